@@ -1,0 +1,135 @@
+/*
+ * tomo_hip.h -- C ABI of libtomo_hip.so, the MI355X (gfx950) implementation of the
+ * mask stack -> scalar field ("SDF") -> marching-cubes mesh path.
+ *
+ * The reference (victorramirez952/tomography_3d_reconstructor) has no FFI: its boundary for
+ * this path is two Python classes (voxel_processor.py:27-164, surface_extractor.py:28-149)
+ * that call NumPy / scipy.ndimage / scikit-image.  This library is what the drop-in classes in
+ * tomography_3d_reconstructor_amd/{voxel_processor,surface_extractor}.py bind with ctypes (see
+ * INTEGRATION.md); every entry point names the reference line(s) it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned (torch-allocated) memory unless the
+ *    parameter name starts with `h_` (host pointer);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
+ *    they never synchronise, allocate or free (exceptions are stated);
+ *  - return value: 0 = ok, negative = TOMO_E_* (never throws across the ABI);
+ *  - volume shape is (nz, ny, nx) = (slices, rows, columns); the padded/field shape is
+ *    (Nz, Ny, Nx) = (nz + 2p, ny + 2p, nx + 2p) with p = pad in {0, 1};
+ *  - "bits" = bit-packed volume: uint64 words, (nz, ny, wx) with wx = tomo_words_per_row(nx);
+ *    bit b of word w of a row is voxel x = 64 w + b; bits at x >= nx are zero.
+ */
+#ifndef TOMO_HIP_H
+#define TOMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOMO_OK 0
+#define TOMO_E_ARG (-1)       /* bad argument (null pointer, non-positive size, ...) */
+#define TOMO_E_LAUNCH (-2)    /* hipGetLastError() after a launch */
+#define TOMO_E_SIZE (-3)      /* a count does not fit the index type used */
+#define TOMO_E_WORKSPACE (-4) /* workspace too small */
+
+int tomo_abi_version(void);
+const char *tomo_error_string(int code);
+/* Host-side probe used by the not-gpu tests: evaluates ONE marching-cubes cell with the same
+ * code the device runs (compiled for the host).  v = 8 corner values (Lewiner order, float32),
+ * tris = up to 36 edge ids (0..12) in LUT order; returns the number of triangles (<0: error). */
+int tomo_host_mc_cell(const float *h_v, double iso, int8_t *h_tris, int *h_uses_centre);
+double tomo_host_mc_edge_offset(double va, double vb);        /* vertex offset along an edge, same code */
+void tomo_host_mc_centre_offset(const double *h_v8, double *h_out3); /* (x,y,z) offset of the centre vertex */
+
+/* ---------------------------------------------------------------- geometry helpers (host, pure) */
+int64_t tomo_words_per_row(int nx);                      /* ceil(nx / 64) */
+/* Extended ("halo") bit volume the field kernel reads: reflect/zero borders materialised. */
+int64_t tomo_ext_words_per_row(int nx, int pad);
+int64_t tomo_ext_rows(int ny, int pad);                  /* ny + 2 pad + 4 */
+int64_t tomo_ext_slices(int nz, int pad);                /* nz + 2 pad + 4 */
+/* Field buffer: float32 (Nz, Ny, pitch); padded column X lives at column tomo_field_xorg + X. */
+int64_t tomo_field_pitch(int nx, int pad);
+int tomo_field_xorg(int pad);                            /* 4 - pad */
+int64_t tomo_mc_segments_per_row(int Nx);                /* ceil(Nx / 256) */
+
+/* ---------------------------------------------------------------- binary stages */
+/* np.stack(mask_images) as uint8 0/1 (voxel_processor.py:46) -> bits. */
+int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, void *stream);
+int tomo_unpack_bits(const uint64_t *bits, uint8_t *mask, int nz, int ny, int nx, void *stream);
+/* np.sum(voxel_data) (voxel_processor.py:51): *count (device uint64) += popcount; caller zeroes it. */
+int tomo_popcount(const uint64_t *bits, int nz, int ny, int nx, unsigned long long *count, void *stream);
+/* ndimage.binary_fill_holes on slice `z` when that slice is non-empty (voxel_processor.py:60-62,66-68).
+ * scratch: ny * wx + 8 words.  Iterates on the device until the flood is stable. */
+int tomo_fill_holes_slice(uint64_t *bits, int nz, int ny, int nx, int z, uint64_t *scratch, void *stream);
+/* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
+ * workspace: tomo_close_ends_workspace_words() uint64 words. */
+int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);
+int tomo_close_ends_scan(uint64_t *bits, int nz, int ny, int nx, uint64_t *workspace, void *stream);
+/* One 6-neighbour pass (skimage binary_erosion/binary_dilation, voxel_processor.py:88,91):
+ * op 0 = erosion with border_value 1, op 1 = dilation with border value 0.  in != out. */
+int tomo_morph_pass(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, int op, void *stream);
+
+/* ---------------------------------------------------------------- scalar field ("SDF") */
+/* bits -> extended bits (reflect of the padded array + zero pad ring), see tomo_ext_*. */
+int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx, int pad, void *stream);
+/* surface_extractor.py:43-53 + the float32 cast of skimage's wrapper: pad, astype(float64),
+ * gaussian_filter(sigma=0.5) (three 5-tap float64 correlate1d passes, axis 0,1,2, mode reflect),
+ * cast to float32.  gaussian = 0 writes the raw 0/1 field (manifold=False). */
+int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
+                    void *stream);
+
+/* ---------------------------------------------------------------- marching cubes (Lewiner MC33) */
+/* Pass 1 (surface_extractor.py:55): per 256-voxel row segment, number of triangles and of
+ * vertices (edge + centre vertices owned by the segment's voxels).
+ * seg_counts: uint32[nseg] packed (ntri << 16 | nvert), nseg = Nz * Ny * segments_per_row. */
+int tomo_mc_count(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                  uint32_t *seg_counts, void *stream);
+/* Exclusive scans of the packed counts: seg_voff/seg_foff uint32[nseg + 1]; totals (device
+ * uint64[4]): {n_vertices, n_triangles, n_active_segments, 0}; active_ids: uint32[nseg] list of
+ * non-empty segments in order (first n_active entries valid).
+ * workspace: tomo_mc_scan_workspace_bytes(nseg) bytes. */
+int64_t tomo_mc_scan_workspace_bytes(int64_t nseg);
+int tomo_mc_scan(const uint32_t *seg_counts, int64_t nseg, uint32_t *seg_voff, uint32_t *seg_foff,
+                 uint32_t *active_ids, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
+                 void *stream);
+/* Pass 2: emit vertices (key + raw MC position, (z,y,x) float32 as skimage returns them) and
+ * faces (three vertex KEYS per triangle, already in the reversed order of
+ * skimage/measure/_marching_cubes_lewiner.py:338).  vertex key = 4 * voxel_linear_index + slot
+ * (slot 0/1/2 = x/y/z edge owned by the voxel, 3 = cell-centre vertex); keys come out ascending. */
+int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                 const uint32_t *seg_voff, const uint32_t *seg_foff, const uint32_t *active_ids,
+                 int64_t n_active, unsigned long long *vkey, float *vpos, unsigned long long *fkey,
+                 void *stream);
+
+/* ---------------------------------------------------------------- mesh finalisation */
+/* surface_extractor.py:57-65 + :82-113 on (V,3) float32 rows in place: -1 shift (if shift),
+ * variable slice depth map of z (cum/adj float64 tables as the reference builds them; nadj = 0
+ * skips it), y *= mm_y, x *= mm_x (float32). */
+int tomo_vertex_finalize(float *vpos, int64_t nv, int shift, const double *cum, int64_t ncum,
+                         const double *adj, int64_t nadj, float mm_y, float mm_x, void *stream);
+/* surface_extractor.py:115-126 (np.unique(axis=0, return_inverse) + drop faces with < 3 distinct
+ * indices), on the device:
+ *   1. lexicographic (z,y,x) sort of the vertex rows, dedupe -> uniq (U,3), rank[V] = final index;
+ *   2. faces: key -> provisional index (search in vkey within the owner segment) -> rank;
+ *      degenerate faces dropped, order kept; written as int64.
+ * Two calls: tomo_mesh_unique (writes *n_unique to totals[0]) then tomo_mesh_faces
+ * (writes the number of kept faces to totals[1]).  Workspace sizes from the *_bytes helpers. */
+int64_t tomo_mesh_unique_workspace_bytes(int64_t nv);
+int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_t *rank, unsigned long long *totals,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);
+int tomo_mesh_faces(const unsigned long long *fkey, int64_t nf, const unsigned long long *vkey, int64_t nv,
+                    const uint32_t *seg_voff, int Ny, int Nx, const int32_t *rank, int64_t *faces_out,
+                    unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
+/* surface_extractor.py:128-149: out[0] = sum over faces of dot(v0, cross(v1,v2))/6 (float64
+ * accumulation of float32 terms), out[1] = sum of 0.5*|cross(v1-v0, v2-v0)|.  out is zeroed by the
+ * caller; tree reduction => parity with the reference's sequential sums is to 1e-6 rel, not bitwise. */
+int tomo_mesh_volume_area(const float *verts, const int64_t *faces, int64_t nf, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOMO_HIP_H */

@@ -1,0 +1,73 @@
+"""CPU tier: the C-ABI library builds for gfx950, loads, and exports every symbol include/tomo_hip.h declares."""
+import ctypes
+import os
+import re
+
+from tomography_3d_reconstructor_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "tomo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tomo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = _lib.build()
+    assert os.path.exists(so)
+    L = ctypes.CDLL(so)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), "missing export: " + s
+        assert s in _lib.SIGNATURES, "no ctypes signature for " + s
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_abi_version_and_error_strings():
+    L = _lib.lib()
+    assert L.tomo_abi_version() == 1
+    assert L.tomo_error_string(0) == b"ok"
+    assert b"argument" in L.tomo_error_string(-1)
+
+
+def test_geometry_helpers():
+    L = _lib.lib()
+    assert L.tomo_words_per_row(1024) == 16 and L.tomo_words_per_row(1025) == 17 and L.tomo_words_per_row(1) == 1
+    assert L.tomo_field_xorg(1) == 3 and L.tomo_field_xorg(0) == 4
+    for nx in (1, 7, 64, 150, 1024, 2048):
+        for pad in (0, 1):
+            pitch = L.tomo_field_pitch(nx, pad)
+            assert pitch % 32 == 0 and pitch >= L.tomo_field_xorg(pad) + nx + 2 * pad
+            assert L.tomo_ext_words_per_row(nx, pad) * 64 >= nx + pad + 6 + 4
+    assert L.tomo_mc_segments_per_row(1026) == 5 and L.tomo_mc_segments_per_row(256) == 1
+
+
+def test_argument_checks_do_not_need_a_gpu():
+    L = _lib.lib()
+    assert L.tomo_pack_bits(None, None, 1, 1, 1, None) == -1
+    assert L.tomo_morph_pass(None, None, 4, 4, 4, 0, None) == -1
+    assert L.tomo_mc_count(None, 4, 4, 4, 4, 0, 0.5, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libtomo_hip.so")
+    with pytest.raises(_lib.TomoError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package (or the drop-in shims) may import,
+    include, link or load it."""
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b|from\s+\.+\s*oracle|oracle[/\\]|libtomo_oracle|tomo_oracle|lewiner_luts\.h)",
+                     re.M)
+    for top in ("tomography_3d_reconstructor_amd", "dropin"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert not bad.search(text), "product file references the oracle: " + os.path.join(dirpath, f)

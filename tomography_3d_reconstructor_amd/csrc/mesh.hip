@@ -1,0 +1,290 @@
+// mesh.hip -- vertex finalisation and the np.unique / face-remap stage on the device.
+//
+// Replaces surface_extractor.py:57-65 (-1 shift, y/x scale), :82-113 (_apply_variable_slice_depths),
+// :115-126 (_ensure_manifold_mesh = np.unique(axis=0, return_inverse) + per-face degenerate filter)
+// and :128-149 (mesh volume / surface area).  The final vertex index of the reference is the rank of
+// the vertex row in the lexicographic (z,y,x) order of the float32 rows, so this is a sort problem:
+// an LSD radix sort (rocPRIM device primitive) of order-preserving uint keys, x first, then (z,y).
+#include <cstring>
+#include <cstdlib>
+#include "tomo_common.h"
+#include <rocprim/rocprim.hpp>
+
+// ------------------------------------------------------------------------------------------ S5-S7
+__global__ __launch_bounds__(256) void vertex_finalize_kernel(float *__restrict__ vpos, int64_t nv, int shift,
+                                                              const double *__restrict__ cum, int64_t ncum,
+                                                              const double *__restrict__ adj, int64_t nadj, float mm_y,
+                                                              float mm_x)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    float *p = vpos + 3 * i;
+    float z = p[0], y = p[1], x = p[2];
+    if (shift) { z -= 1.0f; y -= 1.0f; x -= 1.0f; }
+    if (nadj > 0) {
+        if (z < 0.0f) z = 0.0f;
+        else if ((double)z >= (double)(ncum - 1)) z = (float)cum[ncum - 1];
+        else {
+            int64_t lo = (int64_t)floorf(z);
+            float frac = z - (float)lo;
+            int64_t k = lo < nadj - 1 ? lo : nadj - 1;
+            z = (float)(cum[lo] + (double)frac * adj[k]);
+        }
+    }
+    p[0] = z; p[1] = y * mm_y; p[2] = x * mm_x;
+}
+
+TOMO_API int tomo_vertex_finalize(float *vpos, int64_t nv, int shift, const double *cum, int64_t ncum, const double *adj,
+                                  int64_t nadj, float mm_y, float mm_x, void *stream)
+{
+    if (nv < 0 || (nv > 0 && !vpos) || (nadj > 0 && (!cum || !adj || ncum != nadj + 1))) return TOMO_E_ARG;
+    if (nv == 0) return TOMO_OK;
+    int64_t blocks = ceil_div64(nv, 256);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(vertex_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vpos, nv, shift,
+                       cum, ncum, adj, nadj, mm_y, mm_x);
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------ unique
+__device__ static inline u32 fkey32(float f)
+{   // order-preserving float -> uint
+    u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void uq_init_kernel(const float *__restrict__ vpos, int64_t nv, u32 *__restrict__ kx,
+                                                      u32 *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    kx[i] = fkey32(vpos[3 * i + 2]);
+    idx[i] = (u32)i;
+}
+
+__global__ __launch_bounds__(256) void uq_gather_kernel(const float *__restrict__ vpos, int64_t nv,
+                                                        const u32 *__restrict__ idx, u64 *__restrict__ kzy)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const float *p = vpos + 3 * (int64_t)idx[i];
+    kzy[i] = ((u64)fkey32(p[0]) << 32) | (u64)fkey32(p[1]);
+}
+
+__global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__ vpos, int64_t nv,
+                                                       const u32 *__restrict__ idx, u32 *__restrict__ head)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    u32 h = 1;
+    if (i > 0) {
+        const float *a = vpos + 3 * (int64_t)idx[i], *b = vpos + 3 * (int64_t)idx[i - 1];
+        h = (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
+    }
+    head[i] = h;
+}
+
+__global__ __launch_bounds__(256) void uq_scatter_kernel(const float *__restrict__ vpos, int64_t nv,
+                                                         const u32 *__restrict__ idx, const u32 *__restrict__ head,
+                                                         const u32 *__restrict__ hscan, float *__restrict__ uniq,
+                                                         int32_t *__restrict__ rank, u64 *__restrict__ totals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    u32 u = hscan[i] - 1u;
+    u32 src = idx[i];
+    rank[src] = (int32_t)u;
+    if (head[i]) {
+        const float *p = vpos + 3 * (int64_t)src;
+        float *q = uniq + 3 * (int64_t)u;
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+    }
+    if (i == nv - 1) totals[0] = (u64)hscan[i];
+}
+
+struct UqLayout {
+    size_t kx_a, kx_b, idx_a, idx_b, idx_c, kzy_a, kzy_b, head, hscan, temp, temp_bytes, total;
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static UqLayout uq_layout(int64_t nv)
+{
+    UqLayout L;
+    size_t n = (size_t)(nv > 0 ? nv : 1), off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.kx_a = take(n * 4); L.kx_b = take(n * 4);
+    L.idx_a = take(n * 4); L.idx_b = take(n * 4); L.idx_c = take(n * 4);
+    L.kzy_a = take(n * 8); L.kzy_b = take(n * 8);
+    L.head = take(n * 4); L.hscan = take(n * 4);
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t1, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, n, 0, 32,
+                              (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, t2, (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, n, 0, 64,
+                              (hipStream_t)0);
+    (void)rocprim::inclusive_scan(nullptr, t3, (u32 *)nullptr, (u32 *)nullptr, n, rocprim::plus<u32>(), (hipStream_t)0);
+    L.temp_bytes = t1 > t2 ? t1 : t2;
+    if (t3 > L.temp_bytes) L.temp_bytes = t3;
+    L.temp = take(L.temp_bytes + 256);
+    L.total = off;
+    return L;
+}
+
+TOMO_API int64_t tomo_mesh_unique_workspace_bytes(int64_t nv) { return (int64_t)uq_layout(nv).total; }
+
+TOMO_API int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_t *rank, unsigned long long *totals,
+                              void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!vpos || !uniq || !rank || !totals || !workspace || nv <= 0) return TOMO_E_ARG;
+    if (nv >= 0x7fffffffll) return TOMO_E_SIZE;
+    UqLayout L = uq_layout(nv);
+    if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    u32 *kx_a = (u32 *)(ws + L.kx_a), *kx_b = (u32 *)(ws + L.kx_b);
+    u32 *idx_a = (u32 *)(ws + L.idx_a), *idx_b = (u32 *)(ws + L.idx_b), *idx_c = (u32 *)(ws + L.idx_c);
+    u64 *kzy_a = (u64 *)(ws + L.kzy_a), *kzy_b = (u64 *)(ws + L.kzy_b);
+    u32 *head = (u32 *)(ws + L.head), *hscan = (u32 *)(ws + L.hscan);
+    void *temp = ws + L.temp;
+    size_t tb = L.temp_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned blocks = (unsigned)ceil_div64(nv, 256);
+    hipLaunchKernelGGL(uq_init_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, kx_a, idx_a);
+    if (rocprim::radix_sort_pairs(temp, tb, kx_a, kx_b, idx_a, idx_b, (size_t)nv, 0, 32, s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_gather_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_b, kzy_a);
+    tb = L.temp_bytes;
+    if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 64, s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head);
+    tb = L.temp_bytes;
+    if (rocprim::inclusive_scan(temp, tb, head, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_scatter_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)head,
+                       (const u32 *)hscan, uniq, rank, (u64 *)totals);
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------ faces
+#define KEY_XBITS 20
+__device__ static inline u32 find_vertex(u64 key, const u64 *__restrict__ vkey, const u32 *__restrict__ seg_voff,
+                                         int segs_per_row)
+{
+    u64 row = key >> (KEY_XBITS + 2);
+    u32 X = (u32)(key >> 2) & ((1u << KEY_XBITS) - 1u);
+    u64 seg = row * (u64)segs_per_row + (X >> 8);
+    u32 lo = seg_voff[seg], hi = seg_voff[seg + 1];
+    while (lo < hi) {
+        u32 mid = lo + ((hi - lo) >> 1);
+        u64 k = vkey[mid];
+        if (k < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < seg_voff[seg + 1] && vkey[lo] == key) ? lo : 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256) void faces_resolve_kernel(const u64 *__restrict__ fkey, int64_t nf,
+                                                            const u64 *__restrict__ vkey, const u32 *__restrict__ seg_voff,
+                                                            int segs_per_row, const int32_t *__restrict__ rank,
+                                                            int32_t *__restrict__ ids, u32 *__restrict__ keep,
+                                                            u64 *__restrict__ totals)
+{
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    int32_t id[3];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        u32 p = find_vertex(fkey[3 * f + j], vkey, seg_voff, segs_per_row);
+        if (p == 0xffffffffu) { bad = true; id[j] = -1; }
+        else id[j] = rank ? rank[p] : (int32_t)p;
+    }
+    if (bad) atomicAdd(&totals[3], 1ull);
+    ids[3 * f + 0] = id[0]; ids[3 * f + 1] = id[1]; ids[3 * f + 2] = id[2];
+    keep[f] = (id[0] != id[1] && id[1] != id[2] && id[0] != id[2]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void faces_compact_kernel(const int32_t *__restrict__ ids, const u32 *__restrict__ keep,
+                                                            const u32 *__restrict__ kscan, int64_t nf,
+                                                            int64_t *__restrict__ faces_out, u64 *__restrict__ totals)
+{
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    if (keep[f]) {
+        int64_t o = (int64_t)kscan[f] - 1;
+        faces_out[3 * o + 0] = ids[3 * f + 0];
+        faces_out[3 * o + 1] = ids[3 * f + 1];
+        faces_out[3 * o + 2] = ids[3 * f + 2];
+    }
+    if (f == nf - 1) totals[1] = (u64)kscan[f];
+}
+
+struct FcLayout { size_t ids, keep, kscan, temp, temp_bytes, total; };
+
+static FcLayout fc_layout(int64_t nf)
+{
+    FcLayout L;
+    size_t n = (size_t)(nf > 0 ? nf : 1), off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.ids = take(n * 12); L.keep = take(n * 4); L.kscan = take(n * 4);
+    size_t t = 0;
+    (void)rocprim::inclusive_scan(nullptr, t, (u32 *)nullptr, (u32 *)nullptr, n, rocprim::plus<u32>(), (hipStream_t)0);
+    L.temp_bytes = t;
+    L.temp = take(t + 256);
+    L.total = off;
+    return L;
+}
+
+TOMO_API int64_t tomo_mesh_faces_workspace_bytes(int64_t nf) { return (int64_t)fc_layout(nf).total; }
+
+TOMO_API int tomo_mesh_faces(const unsigned long long *fkey, int64_t nf, const unsigned long long *vkey, int64_t nv,
+                             const uint32_t *seg_voff, int Ny, int Nx, const int32_t *rank, int64_t *faces_out,
+                             unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    (void)Ny;
+    if (!fkey || !vkey || !seg_voff || !faces_out || !totals || !workspace || nf <= 0 || nv <= 0) return TOMO_E_ARG;
+    if (nf >= 0x7fffffffll) return TOMO_E_SIZE;
+    FcLayout L = fc_layout(nf);
+    if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    int32_t *ids = (int32_t *)(ws + L.ids);
+    u32 *keep = (u32 *)(ws + L.keep), *kscan = (u32 *)(ws + L.kscan);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned blocks = (unsigned)ceil_div64(nf, 256);
+    int spr = (int)tomo_mc_segments_per_row(Nx);
+    hipLaunchKernelGGL(faces_resolve_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)fkey, nf, (const u64 *)vkey,
+                       seg_voff, spr, rank, ids, keep, (u64 *)totals);
+    size_t tb = L.temp_bytes;
+    if (rocprim::inclusive_scan(ws + L.temp, tb, keep, kscan, (size_t)nf, rocprim::plus<u32>(), s) != hipSuccess)
+        return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(faces_compact_kernel, dim3(blocks), dim3(256), 0, s, (const int32_t *)ids, (const u32 *)keep,
+                       (const u32 *)kscan, nf, faces_out, (u64 *)totals);
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------ S10/S11
+__global__ __launch_bounds__(256) void volume_area_kernel(const float *__restrict__ v, const int64_t *__restrict__ faces,
+                                                          int64_t nf, double *__restrict__ out)
+{
+    double vol = 0.0, area = 0.0;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += (int64_t)gridDim.x * blockDim.x) {
+        const float *a = v + 3 * faces[3 * f], *b = v + 3 * faces[3 * f + 1], *c = v + 3 * faces[3 * f + 2];
+        // dot(v0, cross(v1, v2)) in float32, then /6.0 in float64 (NumPy 1.x scalar promotion)
+        float cx = b[1] * c[2] - b[2] * c[1], cy = b[2] * c[0] - b[0] * c[2], cz = b[0] * c[1] - b[1] * c[0];
+        float d = a[0] * cx + a[1] * cy + a[2] * cz;
+        vol += (double)d / 6.0;
+        float ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+        float wx = c[0] - a[0], wy = c[1] - a[1], wz = c[2] - a[2];
+        float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+        float nrm = sqrtf(nx * nx + ny * ny + nz * nz);
+        area += (double)(0.5f * nrm);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { vol += __shfl_xor(vol, d, 64); area += __shfl_xor(area, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], vol); atomicAdd(&out[1], area); }
+}
+
+TOMO_API int tomo_mesh_volume_area(const float *verts, const int64_t *faces, int64_t nf, double *out, void *stream)
+{
+    if (!verts || !faces || !out || nf < 0) return TOMO_E_ARG;
+    if (nf == 0) return TOMO_OK;
+    int64_t blocks = ceil_div64(nf, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(volume_area_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, verts, faces, nf, out);
+    return tomo_status();
+}

@@ -1,0 +1,292 @@
+"""Device-resident pipeline: mask stack -> bit volume -> field -> marching cubes -> final mesh.
+
+Everything here operates on torch tensors that live in HBM and launches the hand-written HIP
+kernels of libtomo_hip.so on torch's current stream.  The two drop-in classes
+(voxel_processor.py / surface_extractor.py) are thin host adapters over these functions; bench.py
+times these functions directly with the inputs already resident.
+
+Reference lines each function replaces are given in its docstring.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+@dataclass
+class BitVolume:
+    """Bit-packed boolean volume on the device: int64 words (nz, ny, wx), bit b of word w = voxel 64w+b."""
+    bits: torch.Tensor
+    shape: tuple  # (nz, ny, nx)
+
+    @property
+    def device(self):
+        return self.bits.device
+
+
+@dataclass
+class Field:
+    """float32 field (Nz, Ny, pitch); padded column X is stored at column xorg + X."""
+    data: torch.Tensor
+    Nz: int
+    Ny: int
+    Nx: int
+    pitch: int
+    xorg: int
+
+    def dense(self):
+        return self.data[:, :, self.xorg:self.xorg + self.Nx]
+
+
+@dataclass
+class RawMesh:
+    """Output of marching cubes before finalisation."""
+    vkey: torch.Tensor   # (V,) int64, ascending
+    vpos: torch.Tensor   # (V,3) float32 (z,y,x) as skimage returns them
+    fkey: torch.Tensor   # (F,3) int64 vertex keys, triangle order = reference order
+    seg_voff: torch.Tensor
+    Ny: int
+    Nx: int
+
+
+# ----------------------------------------------------------------------------- binary stages
+def pack(mask: torch.Tensor) -> BitVolume:
+    """np.stack(mask_images) (voxel_processor.py:46) as a device uint8/bool tensor -> BitVolume."""
+    if mask.dim() != 3:
+        raise ValueError("mask must be (nz, ny, nx)")
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    if mask.dtype != torch.uint8:
+        raise TypeError("mask must be bool or uint8")
+    mask = mask.contiguous()
+    nz, ny, nx = mask.shape
+    L = _lib.lib()
+    wx = L.tomo_words_per_row(nx)
+    bits = torch.empty((nz, ny, wx), dtype=torch.int64, device=mask.device)
+    _lib.check(L.tomo_pack_bits(_p(mask), _p(bits), nz, ny, nx, _stream()), "tomo_pack_bits")
+    return BitVolume(bits, (nz, ny, nx))
+
+
+def unpack(vol: BitVolume) -> torch.Tensor:
+    nz, ny, nx = vol.shape
+    out = torch.empty((nz, ny, nx), dtype=torch.uint8, device=vol.device)
+    _lib.check(_lib.lib().tomo_unpack_bits(_p(vol.bits), _p(out), nz, ny, nx, _stream()), "tomo_unpack_bits")
+    return out.view(torch.bool)
+
+
+def popcount_async(vol: BitVolume) -> torch.Tensor:
+    """np.sum(voxel_data) (voxel_processor.py:51) -> 1-element int64 device tensor."""
+    nz, ny, nx = vol.shape
+    cnt = torch.zeros(1, dtype=torch.int64, device=vol.device)
+    _lib.check(_lib.lib().tomo_popcount(_p(vol.bits), nz, ny, nx, _p(cnt), _stream()), "tomo_popcount")
+    return cnt
+
+
+def close_ends(vol: BitVolume) -> BitVolume:
+    """_close_volume_ends (voxel_processor.py:56-77): fill holes of the two end slices, then the z recurrence."""
+    nz, ny, nx = vol.shape
+    L = _lib.lib()
+    out = BitVolume(vol.bits.clone(), vol.shape)
+    wx = out.bits.shape[2]
+    scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=vol.device)
+    _lib.check(L.tomo_fill_holes_slice(_p(out.bits), nz, ny, nx, 0, _p(scratch), _stream()), "tomo_fill_holes_slice")
+    if nz > 1:
+        _lib.check(L.tomo_fill_holes_slice(_p(out.bits), nz, ny, nx, nz - 1, _p(scratch), _stream()),
+                   "tomo_fill_holes_slice")
+    if nz > 2:
+        ws = torch.empty(L.tomo_close_ends_workspace_words(nz, ny, nx), dtype=torch.int64, device=vol.device)
+        _lib.check(L.tomo_close_ends_scan(_p(out.bits), nz, ny, nx, _p(ws), _stream()), "tomo_close_ends_scan")
+    return out
+
+
+def smooth(vol: BitVolume, iterations: int = 3, create_manifold: bool = True) -> BitVolume:
+    """smooth_voxel_data (voxel_processor.py:79-97): opening, then `iterations` closings (3-D cross)."""
+    nz, ny, nx = vol.shape
+    L = _lib.lib()
+    a = vol.bits
+    bufs = [torch.empty_like(a), torch.empty_like(a)]
+    k = 0
+
+    def run(src, op):
+        nonlocal k
+        dst = bufs[k]
+        k ^= 1
+        _lib.check(L.tomo_morph_pass(_p(src), _p(dst), nz, ny, nx, op, _stream()), "tomo_morph_pass")
+        return dst
+
+    cur = a
+    if create_manifold:
+        cur = run(cur, 0)
+        cur = run(cur, 1)
+    for _ in range(int(iterations)):
+        cur = run(cur, 1)
+        cur = run(cur, 0)
+    if cur is a:
+        cur = a.clone()
+    return BitVolume(cur, vol.shape)
+
+
+# ----------------------------------------------------------------------------- field
+def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) -> Field:
+    """surface_extractor.py:43-53 + float32 cast: the scalar field marching cubes reads."""
+    nz, ny, nx = vol.shape
+    L = _lib.lib()
+    pad = 1 if (manifold and add_padding) else 0
+    ez, ey, ewx = L.tomo_ext_slices(nz, pad), L.tomo_ext_rows(ny, pad), L.tomo_ext_words_per_row(nx, pad)
+    ext = torch.empty((ez, ey, ewx), dtype=torch.int64, device=vol.device)
+    _lib.check(L.tomo_extend_bits(_p(vol.bits), _p(ext), nz, ny, nx, pad, _stream()), "tomo_extend_bits")
+    Nz, Ny, Nx = nz + 2 * pad, ny + 2 * pad, nx + 2 * pad
+    pitch = L.tomo_field_pitch(nx, pad)
+    data = torch.empty((Nz, Ny, pitch), dtype=torch.float32, device=vol.device)
+    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _stream()),
+               "tomo_field_fill")
+    return Field(data, Nz, Ny, Nx, pitch, L.tomo_field_xorg(pad))
+
+
+def field_from_dense(dense: torch.Tensor) -> Field:
+    """Wrap an arbitrary float32 (Nz,Ny,Nx) device volume (tests: marching cubes on noise volumes)."""
+    dense = dense.contiguous().to(torch.float32)
+    Nz, Ny, Nx = dense.shape
+    return Field(dense, Nz, Ny, Nx, Nx, 0)
+
+
+# ----------------------------------------------------------------------------- marching cubes
+def marching_cubes(f: Field, level: float = 0.5):
+    """skimage.measure.marching_cubes(volume, level) (surface_extractor.py:55) -> RawMesh or None.
+
+    None stands for the two exceptions of the wrapper that the reference swallows
+    (level outside the data range / no vertices found).
+    """
+    L = _lib.lib()
+    if min(f.Nz, f.Ny, f.Nx) < 2:
+        return None
+    dev = f.data.device
+    spr = L.tomo_mc_segments_per_row(f.Nx)
+    nseg = f.Nz * f.Ny * spr
+    counts = torch.empty(nseg, dtype=torch.int32, device=dev)
+    _lib.check(L.tomo_mc_count(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), _p(counts), _stream()),
+               "tomo_mc_count")
+    seg_voff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    seg_foff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    active = torch.empty(nseg, dtype=torch.int32, device=dev)
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    wsb = L.tomo_mc_scan_workspace_bytes(nseg)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mc_scan(_p(counts), nseg, _p(seg_voff), _p(seg_foff), _p(active), _p(totals), _p(ws), wsb,
+                              _stream()), "tomo_mc_scan")
+    nv, nf, nact, _ = [int(x) for x in totals.cpu()]
+    if nv == 0:
+        return None
+    if nv >= 2 ** 31 or nf >= 2 ** 31:
+        raise _lib.TomoError("mesh too large for 32-bit indices")
+    vkey = torch.empty(nv, dtype=torch.int64, device=dev)
+    vpos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    fkey = torch.empty((max(nf, 1), 3), dtype=torch.int64, device=dev)
+    _lib.check(L.tomo_mc_emit(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), _p(seg_voff), _p(seg_foff),
+                              _p(active), nact, _p(vkey), _p(vpos), _p(fkey), _stream()), "tomo_mc_emit")
+    return RawMesh(vkey, vpos, fkey[:nf], seg_voff, f.Ny, f.Nx)
+
+
+def finalize_vertices(vpos: torch.Tensor, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold=True, add_padding=True):
+    """surface_extractor.py:57-65 and :82-113, in place on the (V,3) float32 device tensor."""
+    d = np.asarray(slice_depths, dtype=np.float64)
+    dev = vpos.device
+    if len(d):
+        adj = np.concatenate([[d[0]], d, [d[-1]]]) if add_padding else d
+        cum = np.cumsum(np.concatenate([[0], adj]))
+        adj_t = torch.from_numpy(np.ascontiguousarray(adj)).to(dev)
+        cum_t = torch.from_numpy(np.ascontiguousarray(cum)).to(dev)
+        nadj, ncum = len(adj), len(cum)
+    else:
+        adj_t = cum_t = None
+        nadj = ncum = 0
+    _lib.check(_lib.lib().tomo_vertex_finalize(_p(vpos), vpos.shape[0], 1 if manifold else 0, _p(cum_t), ncum, _p(adj_t),
+                                               nadj, float(np.float32(mm_per_pixel_y)), float(np.float32(mm_per_pixel_x)),
+                                               _stream()), "tomo_vertex_finalize")
+    return vpos
+
+
+def ensure_manifold_mesh(mesh: RawMesh):
+    """_ensure_manifold_mesh (surface_extractor.py:115-126): unique vertex rows (lexicographic order) and
+    remapped int64 faces without degenerate triangles.  mesh.vpos must already be finalised."""
+    L = _lib.lib()
+    dev = mesh.vpos.device
+    nv, nf = mesh.vpos.shape[0], mesh.fkey.shape[0]
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    uniq = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    rank = torch.empty(nv, dtype=torch.int32, device=dev)
+    wsb = L.tomo_mesh_unique_workspace_bytes(nv)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mesh_unique(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
+               "tomo_mesh_unique")
+    faces = None
+    if nf > 0:
+        faces = torch.empty((nf, 3), dtype=torch.int64, device=dev)
+        wsb2 = L.tomo_mesh_faces_workspace_bytes(nf)
+        ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+        _lib.check(L.tomo_mesh_faces(_p(mesh.fkey), nf, _p(mesh.vkey), nv, _p(mesh.seg_voff), mesh.Ny, mesh.Nx, _p(rank),
+                                     _p(faces), _p(totals), _p(ws2), wsb2, _stream()), "tomo_mesh_faces")
+    nu, nkeep, _, nbad = [int(x) for x in totals.cpu()]
+    if nbad:
+        raise _lib.TomoError("internal error: %d face corners reference a missing vertex" % nbad)
+    verts = uniq[:nu]
+    faces = faces[:nkeep] if faces is not None else torch.empty((0, 3), dtype=torch.int64, device=dev)
+    return verts, faces
+
+
+def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold=True, add_padding=True):
+    """extract_manifold_surface (surface_extractor.py:34-75) on device tensors.
+
+    Returns (vertices (V,3) float32, faces (F,3) int64) device tensors, or None where the reference
+    returns None.
+    """
+    if not manifold:
+        raise NotImplementedError("manifold=False (first-touch vertex numbering) is not built yet")
+    f = make_field(vol, manifold, add_padding)
+    mesh = marching_cubes(f, 0.5)
+    del f
+    if mesh is None:
+        return None
+    finalize_vertices(mesh.vpos, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
+    return ensure_manifold_mesh(mesh)
+
+
+def mesh_volume_area(verts: torch.Tensor, faces: torch.Tensor):
+    """calculate_mesh_volume / calculate_surface_area (surface_extractor.py:128-149) in one pass."""
+    out = torch.zeros(2, dtype=torch.float64, device=verts.device)
+    if faces.shape[0]:
+        _lib.check(_lib.lib().tomo_mesh_volume_area(_p(verts.contiguous()), _p(faces.contiguous()), faces.shape[0],
+                                                    _p(out), _stream()), "tomo_mesh_volume_area")
+    vol, area = out.cpu().tolist()
+    return abs(vol), area
+
+
+def ellipsoid_mask(nz, ny, nx, device, z0=0, z1=None):
+    """Synthetic ellipsoid stack of SURVEY.md 8(d), generated on the device in float64 (bit-identical to the
+    NumPy formula used for the golden hashes).  Optionally only the slab z0 <= z < z1."""
+    z1 = nz if z1 is None else z1
+    cx, cy, cz = (nx - 1) / 2.0, (ny - 1) / 2.0, (nz - 1) / 2.0
+    ax, ay, az = 0.42 * nx, 0.40 * ny, 0.45 * nz
+    x = torch.arange(nx, dtype=torch.float64, device=device)[None, :]
+    y = torch.arange(ny, dtype=torch.float64, device=device)[:, None]
+    ex = ((x - cx) / ax) ** 2
+    ey = ((y - cy) / ay) ** 2
+    exy = (ex + ey)[None]
+    z = torch.arange(z0, z1, dtype=torch.float64, device=device)[:, None, None]
+    ez = ((z - cz) / az) ** 2
+    out = torch.empty((z1 - z0, ny, nx), dtype=torch.bool, device=device)
+    step = max(1, (1 << 26) // (ny * nx))
+    for a in range(0, z1 - z0, step):
+        b = min(z1 - z0, a + step)
+        out[a:b] = (exy + ez[a:b]) <= 1.0
+    return out

@@ -1,0 +1,105 @@
+"""Drop-in for the reference's voxel_processor.py: same class, same methods, same argument meaning
+(/root/reference/voxel_processor.py:27-164), computed by the HIP kernels of libtomo_hip.so.
+
+Host arrays in, host arrays out (the reference's consumers need real np.ndarray); the bit-packed
+device copy of every returned volume is cached (see _devcache) so the orchestrator's next call does
+not upload it again.  There is no CPU fallback: without a GPU / the built library these methods raise.
+"""
+import numpy as np
+import torch
+
+from . import _devcache, pipeline
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise pipeline._lib.TomoError("no MI355X visible: the HIP path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_volume(voxel_data):
+    """ndarray (nz,ny,nx) -> BitVolume, via the cache when the array came from this package."""
+    vol = _devcache.get(voxel_data) if isinstance(voxel_data, np.ndarray) else None
+    if vol is not None:
+        return vol
+    a = np.ascontiguousarray(voxel_data)
+    if a.ndim != 3:
+        raise ValueError("voxel data must be 3-D")
+    if a.dtype != np.bool_:
+        a = a != 0
+    t = torch.from_numpy(a.view(np.uint8)).to(_device(), non_blocking=True)
+    return pipeline.pack(t)
+
+
+def to_host_volume(vol):
+    out = pipeline.unpack(vol).cpu().numpy()
+    _devcache.put(out, vol)
+    return out
+
+
+class VoxelProcessor:
+    """Handles voxel data creation and processing operations (reference: voxel_processor.py:27)."""
+
+    def __init__(self):
+        self.voxel_data = None
+        self.side_0_count = 0
+        self.side_1_count = 0
+        self.side_2_count = 0
+
+    def create_voxel_data(self, mask_images: list, close_ends: bool = True,
+                          side_0_count: int = 0, side_1_count: int = 0, side_2_count: int = 0) -> np.ndarray:
+        """voxel_processor.py:36-54."""
+        if not mask_images:
+            raise ValueError("Load masks first, hmm.")
+        self.side_0_count = side_0_count
+        self.side_1_count = side_1_count
+        self.side_2_count = side_2_count
+        stacked = np.stack(mask_images, axis=0)
+        vol = to_device_volume(stacked)
+        if close_ends:
+            vol = pipeline.close_ends(vol)
+            active = int(pipeline.popcount_async(vol).item())
+            self.voxel_data = to_host_volume(vol)
+        else:
+            active = int(pipeline.popcount_async(vol).item())
+            self.voxel_data = stacked
+            _devcache.put(stacked, vol)
+        print(f"Voxels: {self.voxel_data.shape}, active: {active:,}")
+        return self.voxel_data
+
+    def smooth_voxel_data(self, voxel_data: np.ndarray, iterations: int = 3, create_manifold: bool = True) -> np.ndarray:
+        """voxel_processor.py:79-97 (binary_opening + `iterations` x binary_closing, 3-D cross)."""
+        vol = to_device_volume(voxel_data)
+        return to_host_volume(pipeline.smooth(vol, iterations, create_manifold))
+
+    def generate_point_cloud(self, voxel_data: np.ndarray, mm_per_pixel_x: float, mm_per_pixel_y: float,
+                             slice_depths: np.ndarray, subsample_factor: int = 1) -> np.ndarray:
+        """voxel_processor.py:99-127 (fallback path of the orchestrator; host NumPy, not on the hot path)."""
+        z, y, x = np.where(voxel_data)
+        if subsample_factor > 1:
+            idx = np.arange(0, len(z), subsample_factor)
+            z, y, x = z[idx], y[idx], x[idx]
+        d = np.asarray(slice_depths, dtype=np.float64)
+        cum = np.cumsum(np.concatenate([[0], d]))
+        if len(d):
+            zc = np.minimum(z, len(d) - 1)
+            z_mm = np.where(z < len(d), cum[zc] + d[zc] / 2, cum[-1])
+        else:
+            z_mm = np.full(len(z), cum[-1])
+        return np.column_stack([z_mm, y * mm_per_pixel_y, x * mm_per_pixel_x])
+
+    def calculate_slice_depths(self, total_depth_mm: float) -> np.ndarray:
+        """voxel_processor.py:129-164."""
+        s0, s1, s2 = self.side_0_count, self.side_1_count, self.side_2_count
+        total = s0 + s1 + s2
+        if s1 == 0 or total == 0:
+            if total == 0:
+                return np.array([])
+            return np.full(total, total_depth_mm / total)
+        d1 = total_depth_mm / s1
+        d02 = 2 * d1
+        d0 = d02 / s0 if s0 > 0 else 0
+        d2 = d02 / s2 if s2 > 0 else 0
+        depths = [d0] * s0 + [d1] * s1 + [d2] * s2
+        print(f"Slice depth sequence: Side_0[0-{s0-1}], Side_1[{s0}-{s0+s1-1}], Side_2[{s0+s1}-{len(depths)-1}]")
+        return np.array(depths)
