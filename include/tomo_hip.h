@@ -52,8 +52,8 @@ int64_t tomo_ext_rows(int ny, int pad);                  /* ny + 2 pad + 4 */
 int64_t tomo_ext_slices(int nz, int pad);                /* nz + 2 pad + 4 */
 /* Field buffer: float32 (Nz, Ny, pitch); padded column X lives at column tomo_field_xorg + X. */
 int64_t tomo_field_pitch(int nx, int pad);
-int tomo_field_xorg(int pad);                            /* 4 - pad */
-int64_t tomo_mc_segments_per_row(int Nx);                /* ceil(Nx / 256) */
+int tomo_field_xorg(int pad);                            /* 32 - pad: data column x = 0 sits on a 128-byte line */
+int64_t tomo_mc_segments_per_row(int Nx, int xorg);      /* ceil((xorg + Nx) / 256) */
 
 /* ---------------------------------------------------------------- binary stages */
 /* np.stack(mask_images) as uint8 0/1 (voxel_processor.py:46) -> bits. */
@@ -82,27 +82,46 @@ int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, i
                     void *stream);
 
 /* ---------------------------------------------------------------- marching cubes (Lewiner MC33) */
-/* Pass 1 (surface_extractor.py:55): per 256-voxel row segment, number of triangles and of
- * vertices (edge + centre vertices owned by the segment's voxels).
- * seg_counts: uint32[nseg] packed (ntri << 16 | nvert), nseg = Nz * Ny * segments_per_row. */
-int tomo_mc_count(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                  uint32_t *seg_counts, void *stream);
-/* Exclusive scans of the packed counts: seg_voff/seg_foff uint32[nseg + 1]; totals (device
- * uint64[4]): {n_vertices, n_triangles, n_active_segments, 0}; active_ids: uint32[nseg] list of
- * non-empty segments in order (first n_active entries valid).
- * workspace: tomo_mc_scan_workspace_bytes(nseg) bytes. */
-int64_t tomo_mc_scan_workspace_bytes(int64_t nseg);
-int tomo_mc_scan(const uint32_t *seg_counts, int64_t nseg, uint32_t *seg_voff, uint32_t *seg_foff,
-                 uint32_t *active_ids, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
-                 void *stream);
-/* Pass 2: emit vertices (key + raw MC position, (z,y,x) float32 as skimage returns them) and
- * faces (three vertex KEYS per triangle, already in the reversed order of
- * skimage/measure/_marching_cubes_lewiner.py:338).  vertex key = 4 * voxel_linear_index + slot
- * (slot 0/1/2 = x/y/z edge owned by the voxel, 3 = cell-centre vertex); keys come out ascending. */
+/* skimage.measure.marching_cubes(volume, level) (surface_extractor.py:55) as five device passes.
+ * A SEGMENT = 256 consecutive float columns of a field row (voxel X is in segment (X + xorg) / 256);
+ * nseg = Nz * Ny * tomo_mc_segments_per_row(Nx, xorg).
+ * A voxel is ACTIVE when its 8 cube corners (neighbours clamped at the volume border) are not all on one side
+ * of `iso` (a corner equal to iso counts as below, like the reference).
+ * vertex/voxel key = (row << 22) | (X << 2) | slot, row = Z*Ny + Y; slot 0/1/2 = x/y/z edge owned by the
+ * voxel, 3 = cell-centre vertex (voxel keys have slot 0).
+ *
+ * 1. classify (the only full-volume pass): for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose
+ *    bit L says voxel 4L+k of the segment (X = 256 s + 4L + k - xorg) is active; the call first zeroes the
+ *    whole array (seg_act: uint64[4*nseg]) so empty segments read as 0. */
+int tomo_mc_classify(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                     unsigned long long *seg_act, void *stream);
+/* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of the per-segment active-voxel counts
+ * (popcount of the seg_act record), active_segs uint32[nseg] = indices of the non-empty segments in order,
+ * totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */
+int tomo_mc_scan_segments(const unsigned long long *seg_act, int64_t nseg, uint32_t *seg_aoff, uint32_t *active_segs,
+                          unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
+/* Exclusive scan of packed counts (low 16 bits -> off_a, high 16 bits -> off_b; both uint32[n + 1], off_b may
+ * be NULL), list of the indices of the non-zero entries (nz_ids uint32[n], may be NULL) and
+ * totals (device uint64[4]) = {sum low, sum high, number of non-zero entries, 0}.
+ * workspace: tomo_mc_scan_workspace_bytes(n) bytes. */
+int64_t tomo_mc_scan_workspace_bytes(int64_t n);
+int tomo_mc_scan(const uint32_t *counts, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
+                 unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
+/* 2. list: vox_key[na] = keys of the active voxels, ascending (cell scan order), from seg_act. */
+int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                 const uint32_t *active_segs, int64_t n_active_segs, unsigned long long *vox_key, void *stream);
+/* 3. eval: one MC33 evaluation per active voxel: vox_counts[na] = ntri << 16 | nvert,
+ * vox_flags[na] = bit0/1/2 edge vertices, bit3 centre vertex. */
+int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                 const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags, void *stream);
+/* 4. emit: vertices (key + raw MC position, (z,y,x) float32 as skimage returns them; keys ascending) and
+ * triangles as provisional vertex indices (int32), in the reference's order and with the per-triangle
+ * reversal of skimage/measure/_marching_cubes_lewiner.py:338.  totals[3] counts corners whose vertex was
+ * not found (must stay 0). */
 int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                 const uint32_t *seg_voff, const uint32_t *seg_foff, const uint32_t *active_ids,
-                 int64_t n_active, unsigned long long *vkey, float *vpos, unsigned long long *fkey,
-                 void *stream);
+                 const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff, const uint32_t *vox_voff,
+                 const uint32_t *vox_foff, const uint8_t *vox_flags, unsigned long long *vkey, float *vpos,
+                 int32_t *faces, unsigned long long *totals, void *stream);
 
 /* ---------------------------------------------------------------- mesh finalisation */
 /* surface_extractor.py:57-65 + :82-113 on (V,3) float32 rows in place: -1 shift (if shift),
@@ -112,17 +131,16 @@ int tomo_vertex_finalize(float *vpos, int64_t nv, int shift, const double *cum, 
                          const double *adj, int64_t nadj, float mm_y, float mm_x, void *stream);
 /* surface_extractor.py:115-126 (np.unique(axis=0, return_inverse) + drop faces with < 3 distinct
  * indices), on the device:
- *   1. lexicographic (z,y,x) sort of the vertex rows, dedupe -> uniq (U,3), rank[V] = final index;
- *   2. faces: key -> provisional index (search in vkey within the owner segment) -> rank;
- *      degenerate faces dropped, order kept; written as int64.
- * Two calls: tomo_mesh_unique (writes *n_unique to totals[0]) then tomo_mesh_faces
- * (writes the number of kept faces to totals[1]).  Workspace sizes from the *_bytes helpers. */
+ *   tomo_mesh_unique: lexicographic (z,y,x) sort of the vertex rows, dedupe -> uniq (U,3),
+ *                     rank[V] = final index of every provisional vertex; totals[0] = U;
+ *   tomo_mesh_faces:  faces32 -> rank -> degenerate triangles dropped (order kept) -> int64;
+ *                     totals[1] = number of kept faces.
+ * Workspace sizes from the *_bytes helpers. */
 int64_t tomo_mesh_unique_workspace_bytes(int64_t nv);
 int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_t *rank, unsigned long long *totals,
                      void *workspace, int64_t workspace_bytes, void *stream);
 int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);
-int tomo_mesh_faces(const unsigned long long *fkey, int64_t nf, const unsigned long long *vkey, int64_t nv,
-                    const uint32_t *seg_voff, int Ny, int Nx, const int32_t *rank, int64_t *faces_out,
+int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                     unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* surface_extractor.py:128-149: out[0] = sum over faces of dot(v0, cross(v1,v2))/6 (float64
  * accumulation of float32 terms), out[1] = sum of 0.5*|cross(v1-v0, v2-v0)|.  out is zeroed by the

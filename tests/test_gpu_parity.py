@@ -140,10 +140,10 @@ def test_field_uniform_fast_paths(dev):
 def raw_mesh_as_triangles(mesh):
     vkey = mesh.vkey.cpu().numpy()
     vpos = mesh.vpos.cpu().numpy()
-    fkey = mesh.fkey.cpu().numpy()
+    idx = mesh.faces32.cpu().numpy()
     assert np.all(np.diff(vkey) > 0), "vertex keys must be strictly ascending"
-    idx = np.searchsorted(vkey, fkey)
-    assert np.array_equal(vkey[idx], fkey)
+    assert int(mesh._err[3].item()) == 0
+    assert idx.min() >= 0 and idx.max() < len(vpos)
     return vpos[idx], vpos
 
 

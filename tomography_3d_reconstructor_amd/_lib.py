@@ -31,7 +31,7 @@ SIGNATURES = {
     "tomo_ext_slices": (_c_i64, [_c_i, _c_i]),
     "tomo_field_pitch": (_c_i64, [_c_i, _c_i]),
     "tomo_field_xorg": (_c_i, [_c_i]),
-    "tomo_mc_segments_per_row": (_c_i64, [_c_i]),
+    "tomo_mc_segments_per_row": (_c_i64, [_c_i, _c_i]),
     "tomo_pack_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "tomo_unpack_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "tomo_popcount": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
@@ -41,16 +41,19 @@ SIGNATURES = {
     "tomo_morph_pass": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_extend_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_field_fill": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
-    "tomo_mc_count": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_p]),
+    "tomo_mc_classify": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_p]),
+    "tomo_mc_scan_segments": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mc_scan_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mc_scan": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
-    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p,
-                            _c_p]),
+    "tomo_mc_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "tomo_mc_eval": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                            _c_p, _c_p, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_unique": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mesh_faces_workspace_bytes": (_c_i64, [_c_i64]),
-    "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mesh_volume_area": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_p]),
 }
 

@@ -13,13 +13,16 @@ TOMO_API int64_t tomo_words_per_row(int nx) { return ((int64_t)nx + 63) / 64; }
 TOMO_API int64_t tomo_ext_words_per_row(int nx, int pad) { (void)pad; return ((int64_t)nx + 16 + 63) / 64; }
 TOMO_API int64_t tomo_ext_rows(int ny, int pad) { return (int64_t)ny + 2 * pad + 4; }
 TOMO_API int64_t tomo_ext_slices(int nz, int pad) { return (int64_t)nz + 2 * pad + 4; }
-TOMO_API int tomo_field_xorg(int pad) { return 4 - pad; }
+// Field rows: data column x = 0 sits at float column 32 (a 128-byte line boundary) so that every wave-wide
+// float4 store of the field kernel covers whole 128-byte lines; padded column X is at column xorg + X.
+TOMO_API int tomo_field_xorg(int pad) { return 32 - pad; }
 TOMO_API int64_t tomo_field_pitch(int nx, int pad)
 {
-    int64_t cols = (int64_t)(4 - pad) + nx + 2 * pad;
+    int64_t cols = (int64_t)(32 - pad) + nx + 2 * pad;
     return (cols + 31) / 32 * 32;
 }
-TOMO_API int64_t tomo_mc_segments_per_row(int Nx) { return ((int64_t)Nx + 255) / 256; }
+// marching-cubes segments are 256 float COLUMNS of a field row (16-byte aligned lane loads)
+TOMO_API int64_t tomo_mc_segments_per_row(int Nx, int xorg) { return ((int64_t)Nx + xorg + 255) / 256; }
 
 // ------------------------------------------------------------------------------------------
 // pack: one wave per group of 16 words (1024 voxels) of a row; lane L reads the byte of voxel
@@ -45,6 +48,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ m
     if (lane < 16 && w < wx) bits[row * (int64_t)wx + w] = mine;
 }
 
+// fast variant for rows that are 16-byte aligned (nx % 16 == 0): lane L loads the 16 bytes of voxels
+// 16L..16L+15 of a 1024-voxel group (1 KiB per wave-load), turns them into 16 mask bits with integer
+// arithmetic, and four neighbouring lanes combine their pieces into one 64-bit word.
+__device__ static inline u32 nonzero_nibble(u32 w)
+{   // bit i of the result = (byte i of w != 0)
+    u32 h = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+    return ((h >> 7) * 0x10204080u) >> 28;
+}
+
+__global__ __launch_bounds__(256) void pack16_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits,
+                                                     int64_t rows, int nx, int wx, int groups)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= rows * groups) return;
+    int64_t row = wid / groups;
+    int g = (int)(wid - row * groups);
+    int x = g * 1024 + lane * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x < nx) v = *(const uint4 *)(mask + row * (int64_t)nx + x);
+    u32 piece = nonzero_nibble(v.x) | (nonzero_nibble(v.y) << 4) | (nonzero_nibble(v.z) << 8) | (nonzero_nibble(v.w) << 12);
+    u64 w = (u64)piece << (16 * (lane & 3));
+    w |= __shfl_xor(w, 1, 64);
+    w |= __shfl_xor(w, 2, 64);
+    int word = g * 16 + (lane >> 2);
+    if ((lane & 3) == 0 && word < wx) bits[row * (int64_t)wx + word] = w;
+}
+
 TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, void *stream)
 {
     if (!mask || !bits || nz <= 0 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
@@ -54,8 +85,12 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
     int64_t waves = rows * groups;
     int64_t blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, rows,
-                       nx, wx, groups);
+    if (nx % 16 == 0 && (((uintptr_t)mask) & 15) == 0)
+        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, rows,
+                           nx, wx, groups);
+    else
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, rows,
+                           nx, wx, groups);
     return tomo_status();
 }
 

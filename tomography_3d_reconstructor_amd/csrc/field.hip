@@ -36,6 +36,7 @@ struct FieldParams {
     int nlanes;             // lanes that compute pass 2 (nq, +1 when nx % 4 != 0)
     int r;                  // nx % 4
     int rows_per_block;
+    int W;                  // 32-bit ext words staged per row and block
 };
 
 __device__ static inline double tap5(double a, double b, double c, double d, double e)
@@ -46,12 +47,43 @@ __device__ static inline double tap5(double a, double b, double c, double d, dou
     return t;
 }
 
+#define FIELD_MAX_STAGE_ROWS 36   // rows_per_block (<= 32) + 4
+#define FIELD_NW 10               // 32-bit words that can hold a wave's 256 columns + 2 halo bits on each side
+// LDS: [5 slices][rows_per_block + 4 rows][W words] of the extended bit volume (the block's whole input),
+// followed by the per-(slice, word) OR / AND over the rows (2 x 5 x W words).
+extern __shared__ u32 s_bits[];
+
+// The two pad columns X = 0 and X = Nx-1 of the block's rows, from the values collected in LDS.  Isolated
+// 4-byte stores into otherwise untouched 128-byte lines are ~9x as expensive as whole-line stores on this HBM
+// (read-modify-write), so for the common aligned shape (nx % 32 == 0) the whole line around each pad column is
+// written (zeros elsewhere: those columns are outside the field): 8 rows x 128 B per store instruction.
+__device__ static inline void store_pad_columns(float *obase, const FieldParams &p, float (*s_pad)[32], bool w_first,
+                                                bool w_last, int nrows_out, int lane)
+{
+    if ((p.nx & 31) == 0) {
+        const int q = lane & 7;
+        for (int j = 0; j < nrows_out; j += 8) {
+            const int row = j + (lane >> 3);
+            if (row < nrows_out) {
+                float *o = obase + (int64_t)row * p.pitch;
+                if (w_first) *(float4 *)(o + 4 * q) = make_float4(0.f, 0.f, 0.f, q == 7 ? s_pad[0][row] : 0.f);
+                if (w_last) *(float4 *)(o + 32 + p.nx + 4 * q) = make_float4(q == 0 ? s_pad[1][row] : 0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else if (lane < nrows_out) {
+        float *o = obase + (int64_t)lane * p.pitch;
+        if (w_first) o[p.xorg] = s_pad[0][lane];
+        if (w_last) o[p.xorg + p.Nx - 1] = s_pad[1][lane];
+    }
+}
+
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
                                                            const FieldParams p)
 {
     __shared__ double s_lut[18];
     __shared__ double s_halo[2][16][4];
+    __shared__ float s_pad[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6, T = blockDim.x;
     if (tid < 18) {
         int c = tid / 9, s2 = (tid / 3) % 3, s1 = tid % 3;
@@ -61,17 +93,56 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         s_lut[tid] = t;
     }
     const bool multi = gridDim.x > 1;
-    const int t = multi ? (int)blockIdx.x * (T - 2) + tid - 1 : tid;   // global lane (4-column group) index
+    const int tstart = multi ? (int)blockIdx.x * (T - 2) - 1 : 0;
+    const int t = tstart + tid;                     // global lane (4-column group) index
     const bool valid = t >= 0 && t < p.nlanes;
     const bool can_out = valid && (!multi || (tid > 0 && tid < T - 1));
     const int Z = blockIdx.z;
     const int Y0 = (int)blockIdx.y * p.rows_per_block;
     const int Y1 = Y0 + p.rows_per_block < p.Ny ? Y0 + p.rows_per_block : p.Ny;
-    const int e0 = 4 * t + 4;                      // ext bit == field column of this lane's first element
+    const int nrows = Y1 - Y0 + 4;                  // ext rows Y0 .. Y1+3
+    const int e0 = 4 * t + 4;                       // ext bit of this lane's first element
+    const int col0 = 4 * t + 32;                    // its float column in the field row (128-byte aligned per wave)
     const int sh = e0 & 31;
-    const int64_t sstride = (int64_t)p.EY * p.EWX32;
-    const u32 *base = ext32 + (int64_t)Z * sstride + (valid ? (e0 >> 5) : 0);
+    const int wbase = tstart < 0 ? 0 : (4 * tstart + 2) >> 5;   // word of the block's first halo bit
+    const int W = p.W;
+    const int RS = (p.rows_per_block + 4) * W;      // LDS slice stride
+    u32 *const s_or = s_bits + 5 * RS, *const s_and = s_or + 5 * W;
+    // ---- stage the block's input bits: 5 slices x nrows x W words; thread j < 5*W owns (slice k, word w)
+    if (tid < 5 * W) {
+        const int64_t sstride = (int64_t)p.EY * p.EWX32;
+        const int k = tid / W, w = tid - k * W;
+        const bool inb = wbase + w < p.EWX32;
+        const u32 *sp = ext32 + (int64_t)Z * sstride + (int64_t)Y0 * p.EWX32 + wbase + (int64_t)k * sstride + w;
+        u32 *dp = s_bits + k * RS + w;
+        u32 vor = 0u, vand = 0xffffffffu;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {               // two batches: all loads of a batch are in flight together
+            u32 v[FIELD_MAX_STAGE_ROWS / 2];
+#pragma unroll
+            for (int j = 0; j < FIELD_MAX_STAGE_ROWS / 2; j++) {
+                int yy = h * (FIELD_MAX_STAGE_ROWS / 2) + j;
+                v[j] = (inb && yy < nrows) ? sp[(int64_t)yy * p.EWX32] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < FIELD_MAX_STAGE_ROWS / 2; j++) {
+                int yy = h * (FIELD_MAX_STAGE_ROWS / 2) + j;
+                if (yy < nrows) { dp[yy * W] = v[j]; vor |= v[j]; vand &= v[j]; }
+            }
+        }
+        s_or[tid] = vor; s_and[tid] = vand;
+    }
     __syncthreads();
+    const int wl = valid ? (e0 >> 5) - wbase : 0;   // this lane's word inside the staged rows
+
+    // element k of this lane is padded column X = 4t + k + pad
+    const int Xfirst = 4 * t + p.pad;
+    const bool full4 = can_out && t < p.nq && (Xfirst + 3 < p.Nx);
+    const bool first_lane = (t == 0);
+    const bool last_r0 = (p.r == 0) && (t == p.nq - 1);
+    const int t0w = tstart + wave * 64;
+    const bool w_first = (0 >= t0w) && (0 < t0w + 64);                                 // wave holds lane t = 0
+    const bool w_last = (p.r == 0) && (p.nq - 1 >= t0w) && (p.nq - 1 < t0w + 64);      // wave holds the last_r0 lane
 
     // constants of the all-ones interior, produced by the same operation sequence
     const double p1one = s_lut[17];
@@ -79,20 +150,61 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
     const double c3 = tap5(c2, c2, c2, c2, c2);
     const float c3f = (float)c3;
 
-    // element k of this lane is padded column X = 4t + k + pad
-    const int Xfirst = 4 * t + p.pad;
-    const bool full4 = can_out && t < p.nq && (Xfirst + 3 < p.Nx);
-    const bool first_lane = (t == 0);
-    const bool last_r0 = (p.r == 0) && (t == p.nq - 1);
-
-    // pass-1 code word of ext row ey: 4 bytes, byte k = 9*c + 3*s2 + s1 of column k
-#define LOAD_NIBBLES(ey, n0, n1, n2, n3, n4)                                             \
-    {                                                                                    \
-        const u32 *rp = base + (int64_t)(ey) * p.EWX32;                                  \
-        n0 = rp[0]; n1 = rp[sstride]; n2 = rp[2 * sstride]; n3 = rp[3 * sstride]; n4 = rp[4 * sstride]; \
+    // ---- is the wave's whole neighbourhood (its 256 columns + 2 on each side, all staged rows, 5 slices) constant?
+    int wconst;     // 0 general, 1 all zero, 2 all one
+    {
+        const int ebeg = 4 * t0w + 2 > 0 ? 4 * t0w + 2 : 0, eend = 4 * (t0w + 64) + 6;    // ext bits [ebeg, eend)
+        const int wf = (ebeg >> 5) - wbase, nw = ((eend - 1) >> 5) - wbase - wf + 1;      // nw <= FIELD_NW
+        u32 accor = 0u, accand = 0xffffffffu;
+        if (lane < 5 * FIELD_NW) {
+            const int k = lane / FIELD_NW, j = lane - k * FIELD_NW;
+            if (j < nw && wf + j < W) {
+                const int b0 = (wf + j + wbase) << 5;              // first ext bit of this word
+                u32 m = 0xffffffffu;
+                if (b0 < ebeg) m &= 0xffffffffu << (ebeg - b0);
+                if (b0 + 32 > eend) m &= 0xffffffffu >> (b0 + 32 - eend);
+                accor = s_or[k * W + wf + j] & m;
+                accand = s_and[k * W + wf + j] | ~m;
+            }
+        }
+        const bool allz = __all(accor == 0u), allo = __all(accand == 0xffffffffu);
+        wconst = allz ? 1 : (allo ? 2 : 0);
     }
+    float *const obase = field + ((int64_t)Z * p.Ny + Y0) * p.pitch;
+    if (wconst) {   // publish the (constant) pass-2 halo values for both row parities, once
+        const double k2 = wconst == 1 ? 0.0 : c2;
+        if (lane < 8) s_halo[lane >> 2][wave][lane & 3] = k2;
+    }
+    __syncthreads();
+    if (wconst) {
+        // constant field over the wave's columns for every row of the block: a pure store loop, then the wave
+        // ends (terminated waves no longer take part in the block's barriers)
+        const float kf = wconst == 1 ? 0.0f : c3f;
+        const float4 k4 = make_float4(kf, kf, kf, kf);
+        float *o = obase + col0;
+        if (full4) {
+            for (int Y = Y0; Y < Y1; Y++, o += p.pitch) *(float4 *)o = k4;
+        } else if (can_out) {
+            for (int Y = Y0; Y < Y1; Y++, o += p.pitch) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (Xfirst + k < p.Nx) o[k] = kf;
+            }
+        }
+        if (p.pad && (w_first || w_last)) {                        // pad columns: their bits are zero => wconst == 1
+            if (lane < 32) { if (w_first) s_pad[0][lane] = 0.0f; if (w_last) s_pad[1][lane] = 0.0f; }
+            store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
+        }
+        return;
+    }
+
+    // pass-1 code word of staged row yy: 4 bytes, byte k = 9*c + 3*s2 + s1 of column k
 #define SPREAD(n) ((((n) >> sh) & 0xFu) * 0x00204081u & 0x01010101u)
-#define CODES(n0, n1, n2, n3, n4) (valid ? (SPREAD(n2) * 9u + (SPREAD(n0) + SPREAD(n4)) * 3u + (SPREAD(n1) + SPREAD(n3))) : 0u)
+#define CODES(yy, dst)                                                                          \
+    {                                                                                           \
+        const u32 *rp = s_bits + (yy) * W + wl;                                                 \
+        u32 n0 = rp[0], n1 = rp[RS], n2 = rp[2 * RS], n3 = rp[3 * RS], n4 = rp[4 * RS];         \
+        dst = valid ? (SPREAD(n2) * 9u + (SPREAD(n0) + SPREAD(n4)) * 3u + (SPREAD(n1) + SPREAD(n3))) : 0u; \
+    }
 #define LOOKUP(dst, c)                                    \
     {                                                     \
         dst[0] = s_lut[(c) & 0xffu];                      \
@@ -103,32 +215,23 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
 
     double wa[4], wb[4], wc[4], wd[4], we[4];
     u32 ca, cb, cc, cd, ce;
-    {
-        u32 n0, n1, n2, n3, n4;
-        LOAD_NIBBLES(Y0 + 0, n0, n1, n2, n3, n4); ca = CODES(n0, n1, n2, n3, n4); LOOKUP(wa, ca);
-        LOAD_NIBBLES(Y0 + 1, n0, n1, n2, n3, n4); cb = CODES(n0, n1, n2, n3, n4); LOOKUP(wb, cb);
-        LOAD_NIBBLES(Y0 + 2, n0, n1, n2, n3, n4); cc = CODES(n0, n1, n2, n3, n4); LOOKUP(wc, cc);
-        LOAD_NIBBLES(Y0 + 3, n0, n1, n2, n3, n4); cd = CODES(n0, n1, n2, n3, n4); LOOKUP(wd, cd);
-    }
-    // prefetched raw words of the row that enters the window next
-    u32 m0, m1, m2, m3, m4;
-    LOAD_NIBBLES(Y0 + 4, m0, m1, m2, m3, m4);
+    CODES(0, ca); LOOKUP(wa, ca);
+    CODES(1, cb); LOOKUP(wb, cb);
+    CODES(2, cc); LOOKUP(wc, cc);
+    CODES(3, cd); LOOKUP(wd, cd);
     int buf = 0;
 
-    // one row: window rows (A,B,C,D,E) = Y-2..Y+2, E is filled from the prefetched words
+    // one row: window rows (A,B,C,D,E) = Y-2..Y+2; E enters from staged row (Y - Y0) + 4
 #define STEP(A, B, C, D, E, cA, cB, cC, cD, cE)                                                        \
     {                                                                                                  \
-        cE = CODES(m0, m1, m2, m3, m4);                                                                \
-        {   /* prefetch the next row (clamped: the last prefetch is never used) */                     \
-            int eyn = Y + 5 < p.EY ? Y + 5 : p.EY - 1;                                                 \
-            LOAD_NIBBLES(eyn, m0, m1, m2, m3, m4);                                                     \
-        }                                                                                              \
+        CODES(Y - Y0 + 4, cE);                                                                         \
         const bool z0 = (cA | cB | cC | cD | cE) == 0u;                                                \
         const bool o1 = (cA & cB & cC & cD & cE) == 0x11111111u;                                       \
         const bool wz = __all(z0), wo = __all(o1);                                                     \
+        const bool wu = wz || wo;                                                                      \
+        const double K = wz ? 0.0 : c2;                                                                \
         double q0, q1, q2, q3;                                                                         \
-        if (wz) { q0 = q1 = q2 = q3 = 0.0; E[0] = E[1] = E[2] = E[3] = 0.0; }                          \
-        else if (wo) { q0 = q1 = q2 = q3 = c2; E[0] = E[1] = E[2] = E[3] = p1one; }                    \
+        if (wu) { q0 = q1 = q2 = q3 = K; E[0] = E[1] = E[2] = E[3] = wz ? 0.0 : p1one; }               \
         else {                                                                                         \
             LOOKUP(E, cE);                                                                             \
             q0 = tap5(A[0], B[0], C[0], D[0], E[0]);                                                   \
@@ -138,45 +241,51 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         }                                                                                              \
         if (lane == 0) { s_halo[buf][wave][0] = q0; s_halo[buf][wave][1] = q1; }                       \
         if (lane == 63) { s_halo[buf][wave][2] = q2; s_halo[buf][wave][3] = q3; }                      \
-        double L2 = dpp_from_prev_f64(q2), L3 = dpp_from_prev_f64(q3);                                 \
-        double R0 = dpp_from_next_f64(q0), R1 = dpp_from_next_f64(q1);                                 \
         __syncthreads();                                                                               \
-        if (lane == 0 && wave > 0) { L2 = s_halo[buf][wave - 1][2]; L3 = s_halo[buf][wave - 1][3]; }   \
-        if (lane == 63 && wave < nwaves - 1) { R0 = s_halo[buf][wave + 1][0]; R1 = s_halo[buf][wave + 1][1]; } \
+        /* pass-2 values of the two columns left / right of this lane's four */                        \
+        double L2 = K, L3 = K, R0 = K, R1 = K;                                                         \
+        if (lane == 0) {                                                                               \
+            if (wave > 0) { L2 = s_halo[buf][wave - 1][2]; L3 = s_halo[buf][wave - 1][3]; }            \
+            else { L2 = 0.0; L3 = 0.0; }                                                               \
+        }                                                                                              \
+        if (lane == 63) {                                                                              \
+            if (wave < nwaves - 1) { R0 = s_halo[buf][wave + 1][0]; R1 = s_halo[buf][wave + 1][1]; }   \
+            else { R0 = 0.0; R1 = 0.0; }                                                               \
+        }                                                                                              \
         buf ^= 1;                                                                                      \
         if (first_lane) { L2 = p.pad ? 0.0 : q1; L3 = p.pad ? 0.0 : q0; }                              \
         if (last_r0) { R0 = p.pad ? 0.0 : q3; R1 = p.pad ? 0.0 : q2; }                                 \
         float o0, o1f, o2, o3;                                                                         \
-        const double K = wz ? 0.0 : c2;                                                                \
-        const bool uni = (wz || wo) && __all(L2 == K && L3 == K && R0 == K && R1 == K);                \
+        const bool uni = wu && __all(L2 == K && L3 == K && R0 == K && R1 == K);                        \
         if (uni) { o0 = o1f = o2 = o3 = wz ? 0.0f : c3f; }                                             \
         else {                                                                                         \
+            double l2 = dpp_from_prev_f64(q2), l3 = dpp_from_prev_f64(q3);                             \
+            double r0 = dpp_from_next_f64(q0), r1 = dpp_from_next_f64(q1);                             \
+            if (lane != 0) { L2 = l2; L3 = l3; }                                                       \
+            if (lane != 63) { R0 = r0; R1 = r1; }                                                      \
+            if (first_lane) { L2 = p.pad ? 0.0 : q1; L3 = p.pad ? 0.0 : q0; }                          \
+            if (last_r0) { R0 = p.pad ? 0.0 : q3; R1 = p.pad ? 0.0 : q2; }                             \
             o0 = (float)tap5(L2, L3, q0, q1, q2);                                                      \
             o1f = (float)tap5(L3, q0, q1, q2, q3);                                                     \
             o2 = (float)tap5(q0, q1, q2, q3, R0);                                                      \
             o3 = (float)tap5(q1, q2, q3, R0, R1);                                                      \
         }                                                                                              \
-        float *orow = field + ((int64_t)Z * p.Ny + Y) * p.pitch;                                      \
         if (full4) {                                                                                   \
-            *(float4 *)(orow + e0) = make_float4(o0, o1f, o2, o3);                                     \
+            *(float4 *)(orow + col0) = make_float4(o0, o1f, o2, o3);                                     \
         } else if (can_out) {                                                                          \
-            if (Xfirst + 0 < p.Nx) orow[e0 + 0] = o0;                                                  \
-            if (Xfirst + 1 < p.Nx) orow[e0 + 1] = o1f;                                                 \
-            if (Xfirst + 2 < p.Nx) orow[e0 + 2] = o2;                                                  \
-            if (Xfirst + 3 < p.Nx) orow[e0 + 3] = o3;                                                  \
+            if (Xfirst + 0 < p.Nx) orow[col0 + 0] = o0;                                                  \
+            if (Xfirst + 1 < p.Nx) orow[col0 + 1] = o1f;                                                 \
+            if (Xfirst + 2 < p.Nx) orow[col0 + 2] = o2;                                                  \
+            if (Xfirst + 3 < p.Nx) orow[col0 + 3] = o3;                                                  \
         }                                                                                              \
-        if (p.pad && can_out) {   /* the two pad columns X = 0 and X = Nx-1 (pass-2 value there is 0) */ \
-            if (first_lane) {                                                                          \
-                double s = 0.0; s += (q0 + q1) * FW2; s += q0 * FW1;                                   \
-                orow[p.xorg] = (float)s;                                                               \
-            }                                                                                          \
-            if (last_r0) {                                                                             \
-                double s = 0.0; s += (q2 + q3) * FW2; s += q3 * FW1;                                   \
-                orow[p.xorg + p.Nx - 1] = (float)s;                                                    \
-            }                                                                                          \
+        if (p.pad && can_out) {   /* pad columns X = 0 / Nx-1 (pass-2 value there is 0): kept in LDS, stored once */ \
+            if (first_lane) { double s = 0.0; s += (q0 + q1) * FW2; s += q0 * FW1; s_pad[0][Y - Y0] = (float)s; } \
+            if (last_r0) { double s = 0.0; s += (q2 + q3) * FW2; s += q3 * FW1; s_pad[1][Y - Y0] = (float)s; }   \
         }                                                                                              \
+        orow += p.pitch;                                                                               \
     }
 
+    float *orow = obase;
     int Y = Y0;
     while (Y < Y1) {
         STEP(wa, wb, wc, wd, we, ca, cb, cc, cd, ce); if (++Y >= Y1) break;
@@ -185,11 +294,11 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         STEP(wd, we, wa, wb, wc, cd, ce, ca, cb, cc); if (++Y >= Y1) break;
         STEP(we, wa, wb, wc, wd, ce, ca, cb, cc, cd); ++Y;
     }
+    if (p.pad && (w_first || w_last)) store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
 #undef STEP
 #undef LOOKUP
 #undef CODES
 #undef SPREAD
-#undef LOAD_NIBBLES
 }
 
 // manifold=False: the field is the raw 0/1 volume (surface_extractor.py:46 without the Gaussian).
@@ -222,6 +331,7 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
     p.r = nx % 4;
     p.nlanes = p.nq + (p.r ? 1 : 0);
     p.rows_per_block = 32;
+    p.W = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!gaussian) {
         int64_t total = (int64_t)p.Nz * p.Ny * p.Nx;
@@ -238,10 +348,15 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
         threads = 1024;
         gx = (unsigned)ceil_div64(p.nlanes, threads - 2);
     }
+    p.rows_per_block = threads <= 256 ? 32 : 16;
+    // staged words per row: ext bits [4*tstart + 2, 4*(tstart + threads) + 6) of a block
+    p.W = (4 * threads + 4 + 31) / 32 + 1;
+    if (p.W > p.EWX32) p.W = p.EWX32;
+    size_t lds = ((size_t)5 * (p.rows_per_block + 4) * p.W + 10 * p.W) * sizeof(u32);
     dim3 grid(gx, (unsigned)ceil_div64(p.Ny, p.rows_per_block), (unsigned)p.Nz);
     if (threads <= 256)
-        hipLaunchKernelGGL(field_gauss_kernel<256>, grid, dim3(threads), 0, s, (const u32 *)ext, field, p);
+        hipLaunchKernelGGL(field_gauss_kernel<256>, grid, dim3(threads), lds, s, (const u32 *)ext, field, p);
     else
-        hipLaunchKernelGGL(field_gauss_kernel<1024>, grid, dim3(threads), 0, s, (const u32 *)ext, field, p);
+        hipLaunchKernelGGL(field_gauss_kernel<1024>, grid, dim3(threads), lds, s, (const u32 *)ext, field, p);
     return tomo_status();
 }

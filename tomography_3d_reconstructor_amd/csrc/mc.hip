@@ -1,18 +1,23 @@
-// mc.hip -- Lewiner marching cubes on gfx950 as count -> scan -> emit.
+// mc.hip -- Lewiner marching cubes on gfx950: classify -> compact -> evaluate -> scan -> emit.
 //
 // Replaces skimage.measure.marching_cubes(volume, level=0.5) as called at surface_extractor.py:55
 // (Lewiner MC33, step 1, allow_degenerate=True).  The serial original walks cells z->y->x and numbers
-// vertices by first touch through two "face layers"; here
-//   * a wave owns one SEGMENT = 256 consecutive voxels of a row (4 per lane), in scan order;
-//   * a vertex is identified by the edge it sits on: key = (row << 22 | X << 2 | slot), row = Z*Ny+Y,
-//     slot 0/1/2 = x/y/z edge whose lower corner is the voxel, 3 = cell-centre vertex.  An edge vertex
-//     exists iff the field changes side of the iso level along the edge (every tiling uses exactly the
-//     bichromatic edges of its cube), a centre vertex iff the cell's tiling row contains a 12;
-//   * pass 1 counts triangles and vertices per segment (wave reduction, no atomics),
-//     a three-kernel exclusive scan turns the counts into output offsets and compacts the list of
-//     non-empty segments, pass 2 re-evaluates only those segments and writes vertices and triangles at
-//     their final positions: face order == the reference's cell scan order, LUT order inside a cell.
-// Memory-bound: pass 1 streams the field once (4 B/voxel; the y+1 / z+1 neighbour rows come from L2/MALL).
+// vertices by first touch through two "face layers".  Data-parallel formulation:
+//   * a vertex is identified by the edge it sits on: owner voxel (the edge's lower corner) + slot
+//     (0/1/2 = x/y/z edge, 3 = cell-centre vertex).  An edge vertex exists iff the field changes side of
+//     the iso level along the edge (every MC33 tiling uses exactly the bichromatic edges of its cube);
+//     a centre vertex exists iff the cell's tiling row contains a 12;
+//   * pass 1 (the only full-volume pass, HBM-bound, 4 B/voxel): a wave owns a 256-voxel column SEGMENT
+//     and marches down y with the (y, z) / (y, z+1) rows of its 4 voxels per lane in registers, so each
+//     field value is loaded once per slice pair; it only counts the ACTIVE voxels (8 cube corners not all
+//     on one side) per (row, segment) with ballots -- no MC33 code in the streaming pass;
+//   * scan -> offsets; pass 2 writes the compact, ordered list of active voxels (surface-sized);
+//   * pass 3 evaluates MC33 once per active voxel, ONE VOXEL PER LANE (full lane utilisation for the
+//     branchy code), giving triangle and vertex counts; scan -> output offsets;
+//   * pass 4 writes vertices and triangles at their final positions: triangle order == the reference's
+//     cell scan order, LUT order inside a cell; triangle corners are resolved to vertex indices by a
+//     search in the active list restricted to the owner voxel's segment (a handful of entries).
+// No atomics decide any position: output is deterministic.
 #include "tomo_common.h"
 
 #define MC_LUT_QUAL __device__ const
@@ -21,6 +26,8 @@
 
 #define SEG 256
 #define KEY_XBITS 20
+#define CLS_R 8      // rows of cells per classify task
+#define CLS_ZC 16    // slices per classify task
 
 struct McGrid {
     int Nz, Ny, Nx;
@@ -32,139 +39,181 @@ struct McGrid {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// Loads the 4 voxels of this lane plus the one to the right, for rows (Z,Y),(Z,Y+1),(Z+1,Y),(Z+1,Y+1).
-// Out-of-range neighbours are replaced by clamped coordinates (=> no sign change across the border).
-struct Rows4 {
-    float a[5], b[5], c[5], d[5];   // a: (Z,Y)  b: (Z,Y+1)  c: (Z+1,Y)  d: (Z+1,Y+1)
+__device__ static inline u64 make_key(int64_t row, int X, int slot)
+{
+    return ((u64)row << (KEY_XBITS + 2)) | ((u64)(u32)X << 2) | (u64)slot;
+}
+
+// Lane L of segment s looks at float columns 256 s + 4 L .. + 3 of a field row, i.e. padded voxels
+// X0 .. X0+3 with X0 = 256 s + 4 L - xorg (may start left of the row: voxels with X < 0 do not exist).
+// 5-bit "above iso" mask of X0..X0+4 of one row; values outside [0, Nx) are clamped to the row end (=> no
+// sign change across the border).  Bit 4 comes from the next lane except at the wave / row end.
+// All loads are unconditional and branch-free (a float4 from a clamped start column plus one scalar), so that
+// the compiler can keep every row of a step in flight at once; the clamping is undone on the compare bits.
+struct RowRaw { float4u v; float e; };
+
+__device__ static inline int clampx(int X, int Nx) { return X < 0 ? 0 : (X < Nx ? X : Nx - 1); }
+
+struct LaneGeom {
+    int Xs;        // start of the 4-float load: X0 clamped to [0, Nx-4]
+    int Xe;        // column of the 5th value (X0+4 clamped)
+    int i0, i1, i2, i3;   // which of the 4 loaded floats holds the value of voxel X0+k (clamped)
+    bool own_e;    // the 5th value comes from this lane's scalar load (wave / row end), else from the next lane
 };
 
-__device__ static inline void load_row5(const float *__restrict__ row, int X0, int Nx, int lane, float *out)
+__device__ static inline LaneGeom lane_geom(int X0, int Nx, int lane)
 {
-    // row points at padded column 0
-    if (X0 + 3 < Nx) {
-        float4u v = *(const float4u *)(row + X0);
-        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) { int X = X0 + k < Nx ? X0 + k : Nx - 1; out[k] = X0 < Nx ? row[X] : 0.0f; }
-    }
-    float nxt = dpp_from_next_f32(out[0]);
-    if (lane == 63 || X0 + 4 >= Nx) {
-        int X = X0 + 4 < Nx ? X0 + 4 : Nx - 1;
-        nxt = X0 < Nx ? row[X] : 0.0f;
-    }
-    out[4] = nxt;
+    LaneGeom q;
+    int hi = Nx - 4 > 0 ? Nx - 4 : 0;
+    q.Xs = X0 < 0 ? 0 : (X0 < hi ? X0 : hi);
+    q.Xe = clampx(X0 + 4, Nx);
+    q.i0 = clampx(X0, Nx) - q.Xs; q.i1 = clampx(X0 + 1, Nx) - q.Xs;
+    q.i2 = clampx(X0 + 2, Nx) - q.Xs; q.i3 = clampx(X0 + 3, Nx) - q.Xs;
+    q.own_e = (lane == 63) || (X0 + 4 >= Nx) || (X0 + 4 <= 0);
+    return q;
 }
 
-__device__ static inline void load_rows(const float *__restrict__ field, const McGrid &g, int Z, int Y, int X0, int lane,
-                                        Rows4 &r)
+__device__ static inline RowRaw row_load(const float *__restrict__ row, const LaneGeom &q)
 {
-    int Y1 = Y + 1 < g.Ny ? Y + 1 : g.Ny - 1;
-    int Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
-    const float *pa = field + ((int64_t)Z * g.Ny + Y) * g.pitch + g.xorg;
-    const float *pb = field + ((int64_t)Z * g.Ny + Y1) * g.pitch + g.xorg;
-    const float *pc = field + ((int64_t)Z1 * g.Ny + Y) * g.pitch + g.xorg;
-    const float *pd = field + ((int64_t)Z1 * g.Ny + Y1) * g.pitch + g.xorg;
-    load_row5(pa, X0, g.Nx, lane, r.a);
-    load_row5(pb, X0, g.Nx, lane, r.b);
-    load_row5(pc, X0, g.Nx, lane, r.c);
-    load_row5(pd, X0, g.Nx, lane, r.d);
+    RowRaw r;
+    r.v = *(const float4u *)(row + q.Xs);
+    r.e = row[q.Xe];
+    return r;
 }
 
-// per-voxel evaluation ----------------------------------------------------------------------
-struct VoxelEval {
-    int ntri;
-    int flags;                // bit0 x-edge, bit1 y-edge, bit2 z-edge, bit3 centre
-    const signed char *tris;
-    double v[8];
-};
-
-__device__ static inline void eval_voxel(const Rows4 &r, int k, double iso, bool cell_ok, bool vox_ok, VoxelEval &e)
+// 5-bit "above iso" mask of voxels X0..X0+4 (values outside the row are clamped to its ends)
+__device__ static inline u32 row_mask5(const RowRaw &r, const LaneGeom &q, double iso)
 {
-    e.ntri = 0; e.flags = 0; e.tris = LUT_TILING1;
-    if (!vox_ok) return;
-    e.v[0] = (double)r.a[k] - iso;     e.v[1] = (double)r.a[k + 1] - iso;
-    e.v[2] = (double)r.b[k + 1] - iso; e.v[3] = (double)r.b[k] - iso;
-    e.v[4] = (double)r.c[k] - iso;     e.v[5] = (double)r.c[k + 1] - iso;
-    e.v[6] = (double)r.d[k + 1] - iso; e.v[7] = (double)r.d[k] - iso;
-    int index = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) index |= (e.v[i] > 0.0 ? 1 : 0) << i;
-    int s0 = index & 1;
-    e.flags = (s0 != ((index >> 1) & 1) ? 1 : 0) | (s0 != ((index >> 3) & 1) ? 2 : 0) | (s0 != ((index >> 4) & 1) ? 4 : 0);
-    if (cell_ok && index != 0 && index != 255) {
-        McTiling t = mc_cell_tiling(e.v, index);
-        e.ntri = t.ntri; e.tris = t.tris;
-        if (t.centre) e.flags |= 8;
-    }
+    u32 c = ((double)r.v.x > iso ? 1u : 0u) | ((double)r.v.y > iso ? 2u : 0u) | ((double)r.v.z > iso ? 4u : 0u) |
+            ((double)r.v.w > iso ? 8u : 0u);
+    u32 m = ((c >> q.i0) & 1u) | (((c >> q.i1) & 1u) << 1) | (((c >> q.i2) & 1u) << 2) | (((c >> q.i3) & 1u) << 3);
+    u32 nxt = (u32)dpp_from_next((int)(m & 1u), 0);
+    u32 own = (double)r.e > iso ? 1u : 0u;
+    return m | ((q.own_e ? own : nxt) << 4);
 }
 
-// cheap reject: do the 20 values of this lane straddle the iso level at all?
-__device__ static inline bool lane_has_crossing(const Rows4 &r, double iso)
+// which of the lane's 4 voxels are active, from the masks of rows (Z,Y) (Z,Y+1) (Z+1,Y) (Z+1,Y+1)
+__device__ static inline u32 active_mask4(u32 ma, u32 mb, u32 mc, u32 md, u32 valid)
 {
-    int hi = 0, lo = 0;
+    u32 any = ma | mb | mc | md, all = ma & mb & mc & md;
+    return ((any | (any >> 1)) & ~(all & (all >> 1))) & valid;
+}
+
+__device__ static inline u32 valid_mask4(int X0, int Nx)
+{
+    u32 v = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        hi |= ((double)r.a[k] > iso) | ((double)r.b[k] > iso) | ((double)r.c[k] > iso) | ((double)r.d[k] > iso);
-        lo |= !((double)r.a[k] > iso) | !((double)r.b[k] > iso) | !((double)r.c[k] > iso) | !((double)r.d[k] > iso);
-    }
-    return hi && lo;
+    for (int k = 0; k < 4; k++) v |= (X0 + k >= 0 && X0 + k < Nx) ? (1u << k) : 0u;
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------ pass 1
-__global__ __launch_bounds__(256) void mc_count_kernel(const float *__restrict__ field, const McGrid g, int64_t nseg,
-                                                       u32 *__restrict__ seg_counts)
+// One wave = one task = (segment column s, group of CLS_R rows, chunk of CLS_ZC slices).  It marches along
+// z with the 5-bit masks of the CLS_R + 1 rows of the previous slice in registers, so a field value is
+// loaded (CLS_R+1)/CLS_R * (CLS_ZC+1)/CLS_ZC ~ 1.2 times instead of 4 (2 with row marching only).
+// For every non-empty (row, segment) it writes the four 64-bit ballots (bit L of ballot k = voxel 4L+k of the
+// segment is active) as one aligned 32-byte record into the zero-initialised seg_act array; empty segments are
+// not written at all (isolated 4-byte stores are very expensive on this memory system).
+__global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restrict__ field, const McGrid g, int ngroups,
+                                                          int nzc, int64_t ntasks, u64 *__restrict__ seg_act)
 {
     const int lane = threadIdx.x & 63;
-    int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (seg >= nseg) return;
-    int s = (int)(seg % g.segs_per_row);
-    int64_t row = seg / g.segs_per_row;
-    int Y = (int)(row % g.Ny), Z = (int)(row / g.Ny);
-    int X0 = s * SEG + lane * 4;
-    Rows4 r;
-    load_rows(field, g, Z, Y, X0, lane, r);
-    u32 nt = 0, nv = 0;
-    if (lane_has_crossing(r, g.iso)) {
-        bool zy_ok = (Y + 1 < g.Ny) && (Z + 1 < g.Nz);
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= ntasks) return;
+    const int s = (int)(task % g.segs_per_row);
+    const int64_t tc = task / g.segs_per_row;
+    const int grp = (int)(tc % ngroups);
+    const int zc = (int)(tc / ngroups);
+    const int Y0 = grp * CLS_R;
+    const int Zbeg = zc * CLS_ZC, Zend = Zbeg + CLS_ZC < g.Nz ? Zbeg + CLS_ZC : g.Nz;
+    const int X0 = s * SEG + lane * 4 - g.xorg;
+    const u32 valid = valid_mask4(X0, g.Nx);
+    const LaneGeom q = lane_geom(X0, g.Nx, lane);
+    const float *base = field + g.xorg;
+    int64_t yoff[CLS_R + 1];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            VoxelEval e;
-            int X = X0 + k;
-            eval_voxel(r, k, g.iso, zy_ok && (X + 1 < g.Nx), X < g.Nx, e);
-            nt += (u32)e.ntri;
-            nv += (u32)__popc(e.flags);
-        }
+    for (int r = 0; r <= CLS_R; r++) yoff[r] = (int64_t)(Y0 + r < g.Ny ? Y0 + r : g.Ny - 1) * g.pitch;
+    u32 m0[CLS_R + 1], m1[CLS_R + 1];
+    {
+        RowRaw raw[CLS_R + 1];
+        const float *sl = base + (int64_t)Zbeg * g.Ny * g.pitch;
+#pragma unroll
+        for (int r = 0; r <= CLS_R; r++) raw[r] = row_load(sl + yoff[r], q);
+#pragma unroll
+        for (int r = 0; r <= CLS_R; r++) m0[r] = row_mask5(raw[r], q, g.iso);
     }
-    nt = wave_sum(nt);
-    nv = wave_sum(nv);
-    if (lane == 0) seg_counts[seg] = (nt << 16) | nv;
+    for (int Z = Zbeg; Z < Zend; Z++) {
+        const int Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
+        {
+            RowRaw raw[CLS_R + 1];
+            const float *sl = base + (int64_t)Z1 * g.Ny * g.pitch;
+#pragma unroll
+            for (int r = 0; r <= CLS_R; r++) raw[r] = row_load(sl + yoff[r], q);
+#pragma unroll
+            for (int r = 0; r <= CLS_R; r++) m1[r] = row_mask5(raw[r], q, g.iso);
+        }
+#pragma unroll
+        for (int r = 0; r < CLS_R; r++) {
+            u32 act = active_mask4(m0[r], m0[r + 1], m1[r], m1[r + 1], valid);
+            u64 b0 = __ballot(act & 1u), b1 = __ballot(act & 2u), b2 = __ballot(act & 4u), b3 = __ballot(act & 8u);
+            // only non-empty segments are written (one aligned 32-byte record); the array was zeroed before
+            if ((b0 | b1 | b2 | b3) && Y0 + r < g.Ny && lane < 4) {
+                int64_t seg = ((int64_t)Z * g.Ny + Y0 + r) * g.segs_per_row + s;
+                seg_act[seg * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r <= CLS_R; r++) m0[r] = m1[r];
+    }
 }
 
-TOMO_API int tomo_mc_count(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                           uint32_t *seg_counts, void *stream)
+static inline int make_grid(McGrid &g, const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso)
 {
-    if (!field || !seg_counts || Nz < 2 || Ny < 2 || Nx < 2 || pitch < Nx + xorg) return TOMO_E_ARG;
-    if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
-    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = pitch; g.xorg = xorg; g.iso = iso;
-    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx);
+    if (!field || Nz < 2 || Ny < 2 || Nx < 2 || pitch < Nx + xorg) return TOMO_E_ARG;
+    if (Nx >= (1 << KEY_XBITS) || Nz > 65535) return TOMO_E_SIZE;
+    g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = pitch; g.xorg = xorg; g.iso = iso;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    return TOMO_OK;
+}
+
+TOMO_API int tomo_mc_classify(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                              unsigned long long *seg_act, void *stream)
+{
+    McGrid g;
+    int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
+    if (rc) return rc;
+    if (!seg_act) return TOMO_E_ARG;
     int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row;
-    int64_t blocks = ceil_div64(nseg, 4);
+    if (hipMemsetAsync(seg_act, 0, (size_t)nseg * 32, (hipStream_t)stream) != hipSuccess) return TOMO_E_LAUNCH;
+    int ngroups = (Ny + CLS_R - 1) / CLS_R, nzc = (Nz + CLS_ZC - 1) / CLS_ZC;
+    int64_t ntasks = (int64_t)g.segs_per_row * ngroups * nzc;
+    int64_t blocks = ceil_div64(ntasks, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g, nseg,
-                       seg_counts);
+    hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g, ngroups,
+                       nzc, ntasks, (u64 *)seg_act);
     return tomo_status();
 }
 
 // ------------------------------------------------------------------------------------------ scan
-// Exclusive scan of (nvert, ntri, active) over the segments: block sums -> one-block scan -> apply.
+// Exclusive scan of packed counts (hi 16 bits: b, lo 16 bits: a) plus the compact list of non-zero
+// entries: block sums -> one-block scan -> apply.  Used twice: over segments (a = active voxels) and
+// over active voxels (a = vertices, b = triangles).
 #define SCAN_ITEMS 16
 #define SCAN_BLOCK (256 * SCAN_ITEMS)
 
-struct Sum3 { u64 v, f, a; };
+// count of entry i: either a packed uint32 or, for the segment level, the popcount of a 4 x uint64 ballot record
+__device__ static inline u32 scan_load(const u32 *__restrict__ counts, const u64 *__restrict__ act, int64_t i)
+{
+    if (act) {
+        const ulonglong2 *q = (const ulonglong2 *)(act + 4 * i);
+        ulonglong2 a = q[0], b = q[1];
+        return (u32)(__popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y));
+    }
+    return counts[i];
+}
 
-__global__ __launch_bounds__(256) void scan_reduce_kernel(const u32 *__restrict__ counts, int64_t nseg,
-                                                          u64 *__restrict__ bsum)
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const u32 *__restrict__ counts, const u64 *__restrict__ act,
+                                                          int64_t n, u64 *__restrict__ bsum)
 {
     __shared__ u64 sv[4], sf[4], sa[4];
     int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
@@ -172,7 +221,7 @@ __global__ __launch_bounds__(256) void scan_reduce_kernel(const u32 *__restrict_
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         int64_t i = base + k;
-        u32 c = i < nseg ? counts[i] : 0u;
+        u32 c = i < n ? scan_load(counts, act, i) : 0u;
         v += c & 0xffffu; f += c >> 16; a += c != 0u;
     }
     v = wave_sum64(v); f = wave_sum64(f); a = wave_sum64(a);
@@ -196,10 +245,9 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(u64 *__restrict__ bsum
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t start = 0; start < nblocks; start += 256) {
         int64_t i = start + threadIdx.x;
-        u64 x[3];
+        u64 x[3], inc[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) x[c] = i < nblocks ? bsum[3 * i + c] : 0ull;
-        u64 inc[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             u64 v = x[c];
@@ -219,16 +267,17 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(u64 *__restrict__ bsum
             if (i < nblocks) bsum[3 * i + c] = off + inc[c] - x[c];
         }
         __syncthreads();
-        if (threadIdx.x < 3) carry[threadIdx.x] += wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
+        if (threadIdx.x < 3)
+            carry[threadIdx.x] += wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
         __syncthreads();
     }
     if (threadIdx.x < 3) totals[threadIdx.x] = carry[threadIdx.x];
     if (threadIdx.x == 3) totals[3] = 0;
 }
 
-__global__ __launch_bounds__(256) void scan_apply_kernel(const u32 *__restrict__ counts, int64_t nseg,
-                                                         const u64 *__restrict__ bsum, u32 *__restrict__ seg_voff,
-                                                         u32 *__restrict__ seg_foff, u32 *__restrict__ active_ids)
+__global__ __launch_bounds__(256) void scan_apply_kernel(const u32 *__restrict__ counts, const u64 *__restrict__ act,
+                                                         int64_t n, const u64 *__restrict__ bsum, u32 *__restrict__ off_a,
+                                                         u32 *__restrict__ off_b, u32 *__restrict__ nz_ids)
 {
     __shared__ u64 wv[4], wf[4], wa[4];
     int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
@@ -237,10 +286,9 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const u32 *__restrict__
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         int64_t i = base + k;
-        c[k] = i < nseg ? counts[i] : 0u;
+        c[k] = i < n ? scan_load(counts, act, i) : 0u;
         v += c[k] & 0xffffu; f += c[k] >> 16; a += c[k] != 0u;
     }
-    // exclusive scan of the per-thread sums across the block
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u64 iv = v, jf = f, ia = a;
 #pragma unroll
@@ -256,141 +304,274 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const u32 *__restrict__
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         int64_t i = base + k;
-        if (i < nseg) {
-            seg_voff[i] = (u32)ov; seg_foff[i] = (u32)of;
-            if (c[k]) active_ids[oa] = (u32)i;
+        if (i < n) {
+            off_a[i] = (u32)ov;
+            if (off_b) off_b[i] = (u32)of;
+            if (nz_ids && c[k]) nz_ids[oa] = (u32)i;
         }
         ov += c[k] & 0xffffu; of += c[k] >> 16; oa += c[k] != 0u;
     }
-    // the thread that owns the last segment writes the end sentinels
-    if (base <= nseg - 1 && nseg - 1 < base + SCAN_ITEMS) { seg_voff[nseg] = (u32)ov; seg_foff[nseg] = (u32)of; }
+    if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) {   // end sentinels
+        off_a[n] = (u32)ov;
+        if (off_b) off_b[n] = (u32)of;
+    }
 }
 
-TOMO_API int64_t tomo_mc_scan_workspace_bytes(int64_t nseg)
+TOMO_API int64_t tomo_mc_scan_workspace_bytes(int64_t n)
 {
-    return (ceil_div64(nseg, SCAN_BLOCK) * 3 + 8) * (int64_t)sizeof(u64);
+    return (ceil_div64(n > 0 ? n : 1, SCAN_BLOCK) * 3 + 8) * (int64_t)sizeof(u64);
 }
 
-TOMO_API int tomo_mc_scan(const uint32_t *seg_counts, int64_t nseg, uint32_t *seg_voff, uint32_t *seg_foff,
-                          uint32_t *active_ids, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
-                          void *stream)
+static int scan_launch(const u32 *counts, const u64 *act, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
+                       unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    if (!seg_counts || !seg_voff || !seg_foff || !active_ids || !totals || !workspace || nseg <= 0) return TOMO_E_ARG;
-    if (nseg >= 0xffffffffll) return TOMO_E_SIZE;
-    if (workspace_bytes < tomo_mc_scan_workspace_bytes(nseg)) return TOMO_E_WORKSPACE;
-    int64_t nblocks = ceil_div64(nseg, SCAN_BLOCK);
+    if ((!counts && !act) || !off_a || !totals || !workspace || n <= 0) return TOMO_E_ARG;
+    if (n >= 0xffffffffll) return TOMO_E_SIZE;
+    if (workspace_bytes < tomo_mc_scan_workspace_bytes(n)) return TOMO_E_WORKSPACE;
+    int64_t nblocks = ceil_div64(n, SCAN_BLOCK);
     u64 *bsum = (u64 *)workspace;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, seg_counts, nseg, bsum);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, counts, act, n, bsum);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, bsum, nblocks, (u64 *)totals);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, seg_counts, nseg, (const u64 *)bsum,
-                       seg_voff, seg_foff, active_ids);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, counts, act, n, (const u64 *)bsum,
+                       off_a, off_b, nz_ids);
     return tomo_status();
 }
 
-// ------------------------------------------------------------------------------------------ pass 2
-__device__ static inline u64 make_key(int64_t row, int X, int slot)
+TOMO_API int tomo_mc_scan(const uint32_t *counts, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
+                          unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return ((u64)row << (KEY_XBITS + 2)) | ((u64)(u32)X << 2) | (u64)slot;
+    return scan_launch(counts, nullptr, n, off_a, off_b, nz_ids, totals, workspace, workspace_bytes, stream);
+}
+
+TOMO_API int tomo_mc_scan_segments(const unsigned long long *seg_act, int64_t nseg, uint32_t *seg_aoff,
+                                   uint32_t *active_segs, unsigned long long *totals, void *workspace,
+                                   int64_t workspace_bytes, void *stream)
+{
+    return scan_launch(nullptr, (const u64 *)seg_act, nseg, seg_aoff, nullptr, active_segs, totals, workspace,
+                       workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------ pass 2
+// one LANE per active segment (consecutive lanes write consecutive ranges of vox_key): expand the four
+// ballots written by pass 1 into voxel keys, in x order
+__global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
+                                                      const u64 *__restrict__ seg_act, const u32 *__restrict__ active_segs,
+                                                      int64_t n_active_segs, u64 *__restrict__ vox_key)
+{
+    int64_t ai = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ai >= n_active_segs) return;
+    int64_t seg = active_segs[ai];
+    int s = (int)(seg % g.segs_per_row);
+    int64_t row = seg / g.segs_per_row;
+    const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
+    ulonglong2 lo = q[0], hi = q[1];
+    u64 b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
+    u32 o = seg_aoff[seg];
+    const int Xs = s * SEG - g.xorg;
+    u64 any = b0 | b1 | b2 | b3;
+    while (any) {                                   // lanes (groups of 4 voxels) that hold an active voxel, ascending
+        int L = __ffsll((long long)any) - 1;
+        any &= any - 1;
+        int X0 = Xs + 4 * L;
+        if ((b0 >> L) & 1ull) vox_key[o++] = make_key(row, X0, 0);
+        if ((b1 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 1, 0);
+        if ((b2 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 2, 0);
+        if ((b3 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 3, 0);
+    }
+}
+
+TOMO_API int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                          const uint32_t *active_segs, int64_t n_active_segs, unsigned long long *vox_key, void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_aoff || !seg_act || !active_segs || !vox_key) return TOMO_E_ARG;
+    if (n_active_segs <= 0) return TOMO_OK;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    int64_t blocks = ceil_div64(n_active_segs, 256);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc_list_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, seg_aoff,
+                       (const u64 *)seg_act, active_segs, n_active_segs, (u64 *)vox_key);
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------ pass 3 / 4
+struct Cell {
+    double v[8];       // corner values minus iso, Lewiner order
+    int index;
+    bool cell_ok;
+    int flags;         // bit0/1/2: x/y/z edge vertex owned by this voxel, bit3: centre vertex
+    int Z, Y, X;
+    int64_t row;
+};
+
+__device__ static inline void load_cell(const float *__restrict__ field, const McGrid &g, u64 key, Cell &c)
+{
+    c.row = (int64_t)(key >> (KEY_XBITS + 2));
+    c.X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
+    c.Y = (int)(c.row % g.Ny);
+    c.Z = (int)(c.row / g.Ny);
+    int X1 = c.X + 1 < g.Nx ? c.X + 1 : g.Nx - 1;
+    int Y1 = c.Y + 1 < g.Ny ? c.Y + 1 : g.Ny - 1;
+    int Z1 = c.Z + 1 < g.Nz ? c.Z + 1 : g.Nz - 1;
+    c.cell_ok = (c.X + 1 < g.Nx) && (c.Y + 1 < g.Ny) && (c.Z + 1 < g.Nz);
+    const float *r00 = field + ((int64_t)c.Z * g.Ny + c.Y) * g.pitch + g.xorg;
+    const float *r01 = field + ((int64_t)c.Z * g.Ny + Y1) * g.pitch + g.xorg;
+    const float *r10 = field + ((int64_t)Z1 * g.Ny + c.Y) * g.pitch + g.xorg;
+    const float *r11 = field + ((int64_t)Z1 * g.Ny + Y1) * g.pitch + g.xorg;
+    c.v[0] = (double)r00[c.X] - g.iso; c.v[1] = (double)r00[X1] - g.iso;
+    c.v[2] = (double)r01[X1] - g.iso;  c.v[3] = (double)r01[c.X] - g.iso;
+    c.v[4] = (double)r10[c.X] - g.iso; c.v[5] = (double)r10[X1] - g.iso;
+    c.v[6] = (double)r11[X1] - g.iso;  c.v[7] = (double)r11[c.X] - g.iso;
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) idx |= (c.v[i] > 0.0 ? 1 : 0) << i;
+    c.index = idx;
+    int s0 = idx & 1;
+    c.flags = (s0 != ((idx >> 1) & 1) ? 1 : 0) | (s0 != ((idx >> 3) & 1) ? 2 : 0) | (s0 != ((idx >> 4) & 1) ? 4 : 0);
+}
+
+__global__ __launch_bounds__(256) void mc_eval_kernel(const float *__restrict__ field, const McGrid g,
+                                                      const u64 *__restrict__ vox_key, int64_t na,
+                                                      u32 *__restrict__ vox_counts, uint8_t *__restrict__ vox_flags)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    Cell c;
+    load_cell(field, g, vox_key[i], c);
+    int ntri = 0;
+    if (c.cell_ok && c.index != 0 && c.index != 255) {
+        McTiling t = mc_cell_tiling(c.v, c.index);
+        ntri = t.ntri;
+        if (t.centre) c.flags |= 8;
+    }
+    vox_counts[i] = ((u32)ntri << 16) | (u32)__popc(c.flags);
+    vox_flags[i] = (uint8_t)c.flags;
+}
+
+TOMO_API int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                          const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags,
+                          void *stream)
+{
+    McGrid g;
+    int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
+    if (rc) return rc;
+    if (!vox_key || !vox_counts || !vox_flags) return TOMO_E_ARG;
+    if (na <= 0) return TOMO_OK;
+    int64_t blocks = ceil_div64(na, 256);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
+                       (const u64 *)vox_key, na, vox_counts, vox_flags);
+    return tomo_status();
+}
+
+// index of the vertex (owner voxel key, slot): search the active list inside the owner's segment
+__device__ static inline u32 find_vertex(u64 okey, int slot, const McGrid &g, const u64 *__restrict__ vox_key,
+                                         const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
+                                         const uint8_t *__restrict__ vox_flags)
+{
+    u64 row = okey >> (KEY_XBITS + 2);
+    u32 X = (u32)(okey >> 2) & ((1u << KEY_XBITS) - 1u);
+    u64 seg = row * (u64)g.segs_per_row + ((X + (u32)g.xorg) >> 8);
+    u32 lo = seg_aoff[seg], end = seg_aoff[seg + 1], hi = end;
+    while (lo < hi) {
+        u32 mid = lo + ((hi - lo) >> 1);
+        if (vox_key[mid] < okey) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= end || vox_key[lo] != okey) return 0xffffffffu;
+    u32 fl = vox_flags[lo];
+    if (!(fl & (1u << slot))) return 0xffffffffu;
+    return vox_voff[lo] + (u32)__popc(fl & ((1u << slot) - 1u));
 }
 
 __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ field, const McGrid g,
-                                                      const u32 *__restrict__ seg_voff, const u32 *__restrict__ seg_foff,
-                                                      const u32 *__restrict__ active_ids, int64_t n_active,
+                                                      const u64 *__restrict__ vox_key, int64_t na,
+                                                      const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
+                                                      const u32 *__restrict__ vox_foff, const uint8_t *__restrict__ vox_flags,
                                                       u64 *__restrict__ vkey, float *__restrict__ vpos,
-                                                      u64 *__restrict__ fkey)
+                                                      int32_t *__restrict__ faces, u64 *__restrict__ totals)
 {
-    const int lane = threadIdx.x & 63;
-    int64_t ai = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ai >= n_active) return;
-    int64_t seg = active_ids[ai];
-    int s = (int)(seg % g.segs_per_row);
-    int64_t row = seg / g.segs_per_row;
-    int Y = (int)(row % g.Ny), Z = (int)(row / g.Ny);
-    int X0 = s * SEG + lane * 4;
-    Rows4 r;
-    load_rows(field, g, Z, Y, X0, lane, r);
-    const bool zy_ok = (Y + 1 < g.Ny) && (Z + 1 < g.Nz);
-    const bool crossing = lane_has_crossing(r, g.iso);
-    // first sweep: this lane's totals
-    u32 nt = 0, nv = 0;
-    if (crossing) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            VoxelEval e;
-            int X = X0 + k;
-            eval_voxel(r, k, g.iso, zy_ok && (X + 1 < g.Nx), X < g.Nx, e);
-            nt += (u32)e.ntri; nv += (u32)__popc(e.flags);
-        }
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    Cell c;
+    u64 key = vox_key[i];
+    load_cell(field, g, key, c);
+    const int flags = vox_flags[i];
+    u32 vo = vox_voff[i];
+    const float fZ = (float)c.Z, fY = (float)c.Y, fX = (float)c.X;
+    if (flags & 1) {
+        vkey[vo] = key | 0ull;
+        float *p = vpos + 3 * (int64_t)vo;
+        p[0] = fZ; p[1] = fY; p[2] = (float)((double)c.X + mc_edge_offset(c.v[0], c.v[1]));
+        vo++;
     }
-    u32 voff = seg_voff[seg] + wave_inclusive_scan(nv) - nv;
-    u32 foff = seg_foff[seg] + wave_inclusive_scan(nt) - nt;
-    if (!crossing) return;
-    // second sweep: write
+    if (flags & 2) {
+        vkey[vo] = key | 1ull;
+        float *p = vpos + 3 * (int64_t)vo;
+        p[0] = fZ; p[1] = (float)((double)c.Y + mc_edge_offset(c.v[0], c.v[3])); p[2] = fX;
+        vo++;
+    }
+    if (flags & 4) {
+        vkey[vo] = key | 2ull;
+        float *p = vpos + 3 * (int64_t)vo;
+        p[0] = (float)((double)c.Z + mc_edge_offset(c.v[0], c.v[4])); p[1] = fY; p[2] = fX;
+        vo++;
+    }
+    if (flags & 8) {
+        double ox, oy, oz;
+        mc_centre_offset(c.v, &ox, &oy, &oz);
+        vkey[vo] = key | 3ull;
+        float *p = vpos + 3 * (int64_t)vo;
+        p[0] = (float)((double)c.Z + oz); p[1] = (float)((double)c.Y + oy); p[2] = (float)((double)c.X + ox);
+        vo++;
+    }
+    if (!(c.cell_ok && c.index != 0 && c.index != 255)) return;
+    McTiling t = mc_cell_tiling(c.v, c.index);
+    u32 fo = vox_foff[i];
     const int64_t rowY = (int64_t)g.Ny;
+    bool bad = false;
+    for (int tI = 0; tI < t.ntri; tI++) {
+        int32_t id[3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        VoxelEval e;
-        int X = X0 + k;
-        eval_voxel(r, k, g.iso, zy_ok && (X + 1 < g.Nx), X < g.Nx, e);
-        if (e.flags & 1) {
-            vkey[voff] = make_key(row, X, 0);
-            float *p = vpos + 3 * (int64_t)voff;
-            p[0] = (float)Z; p[1] = (float)Y; p[2] = (float)((double)X + mc_edge_offset(e.v[0], e.v[1]));
-            voff++;
-        }
-        if (e.flags & 2) {
-            vkey[voff] = make_key(row, X, 1);
-            float *p = vpos + 3 * (int64_t)voff;
-            p[0] = (float)Z; p[1] = (float)((double)Y + mc_edge_offset(e.v[0], e.v[3])); p[2] = (float)X;
-            voff++;
-        }
-        if (e.flags & 4) {
-            vkey[voff] = make_key(row, X, 2);
-            float *p = vpos + 3 * (int64_t)voff;
-            p[0] = (float)((double)Z + mc_edge_offset(e.v[0], e.v[4])); p[1] = (float)Y; p[2] = (float)X;
-            voff++;
-        }
-        if (e.flags & 8) {
-            double ox, oy, oz;
-            mc_centre_offset(e.v, &ox, &oy, &oz);
-            vkey[voff] = make_key(row, X, 3);
-            float *p = vpos + 3 * (int64_t)voff;
-            p[0] = (float)((double)Z + oz); p[1] = (float)((double)Y + oy); p[2] = (float)((double)X + ox);
-            voff++;
-        }
-        for (int tI = 0; tI < e.ntri; tI++) {
-            u64 kk[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                int ed = e.tris[3 * tI + j];
-                // owner voxel of the edge and its slot
-                int dx = (ed == 1 || ed == 5 || ed == 9 || ed == 10) ? 1 : 0;
-                int dy = (ed == 2 || ed == 6 || ed == 10 || ed == 11) ? 1 : 0;
-                int dz = (ed >= 4 && ed <= 7) ? 1 : 0;
-                int slot = ed == 12 ? 3 : (ed >= 8 ? 2 : (ed & 1));
-                kk[j] = make_key(row + dy + dz * rowY, X + dx, slot);
+        for (int j = 0; j < 3; j++) {
+            int ed = t.tris[3 * tI + j];
+            int dx = (ed == 1 || ed == 5 || ed == 9 || ed == 10) ? 1 : 0;
+            int dy = (ed == 2 || ed == 6 || ed == 10 || ed == 11) ? 1 : 0;
+            int dz = (ed >= 4 && ed <= 7) ? 1 : 0;
+            int slot = ed == 12 ? 3 : (ed >= 8 ? 2 : (ed & 1));
+            u32 v;
+            if ((dx | dy | dz) == 0) {           // owned by this voxel: no search
+                v = vox_voff[i] + (u32)__popc(flags & ((1 << slot) - 1));
+                if (!(flags & (1 << slot))) v = 0xffffffffu;
+            } else {
+                v = find_vertex(make_key(c.row + dy + dz * rowY, c.X + dx, 0), slot, g, vox_key, seg_aoff, vox_voff,
+                                vox_flags);
             }
-            u64 *fp = fkey + 3 * (int64_t)foff;
-            fp[0] = kk[2]; fp[1] = kk[1]; fp[2] = kk[0];   // np.fliplr(faces) of the wrapper
-            foff++;
+            bad |= (v == 0xffffffffu);
+            id[j] = (int32_t)v;
         }
+        int32_t *fp = faces + 3 * (int64_t)fo;
+        fp[0] = id[2]; fp[1] = id[1]; fp[2] = id[0];   // np.fliplr(faces) of the skimage wrapper
+        fo++;
     }
+    if (bad) atomicAdd(&totals[3], 1ull);
 }
 
 TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                          const uint32_t *seg_voff, const uint32_t *seg_foff, const uint32_t *active_ids,
-                          int64_t n_active, unsigned long long *vkey, float *vpos, unsigned long long *fkey,
-                          void *stream)
+                          const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
+                          const uint32_t *vox_voff, const uint32_t *vox_foff, const uint8_t *vox_flags,
+                          unsigned long long *vkey, float *vpos, int32_t *faces, unsigned long long *totals, void *stream)
 {
-    if (!field || !seg_voff || !seg_foff || !active_ids || !vkey || !vpos || !fkey || Nz < 2 || Ny < 2 || Nx < 2)
+    McGrid g;
+    int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
+    if (rc) return rc;
+    if (!vox_key || !seg_aoff || !vox_voff || !vox_foff || !vox_flags || !vkey || !vpos || !faces || !totals)
         return TOMO_E_ARG;
-    if (n_active <= 0) return TOMO_OK;
-    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = pitch; g.xorg = xorg; g.iso = iso;
-    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx);
-    int64_t blocks = ceil_div64(n_active, 4);
+    if (na <= 0) return TOMO_OK;
+    int64_t blocks = ceil_div64(na, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g, seg_voff,
-                       seg_foff, active_ids, n_active, (u64 *)vkey, vpos, (u64 *)fkey);
+    hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
+                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_foff, vox_flags, (u64 *)vkey, vpos, faces,
+                       (u64 *)totals);
     return tomo_status();
 }

@@ -162,41 +162,17 @@ TOMO_API int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_
 }
 
 // ------------------------------------------------------------------------------------------ faces
-#define KEY_XBITS 20
-__device__ static inline u32 find_vertex(u64 key, const u64 *__restrict__ vkey, const u32 *__restrict__ seg_voff,
-                                         int segs_per_row)
-{
-    u64 row = key >> (KEY_XBITS + 2);
-    u32 X = (u32)(key >> 2) & ((1u << KEY_XBITS) - 1u);
-    u64 seg = row * (u64)segs_per_row + (X >> 8);
-    u32 lo = seg_voff[seg], hi = seg_voff[seg + 1];
-    while (lo < hi) {
-        u32 mid = lo + ((hi - lo) >> 1);
-        u64 k = vkey[mid];
-        if (k < key) lo = mid + 1; else hi = mid;
-    }
-    return (lo < seg_voff[seg + 1] && vkey[lo] == key) ? lo : 0xffffffffu;
-}
-
-__global__ __launch_bounds__(256) void faces_resolve_kernel(const u64 *__restrict__ fkey, int64_t nf,
-                                                            const u64 *__restrict__ vkey, const u32 *__restrict__ seg_voff,
-                                                            int segs_per_row, const int32_t *__restrict__ rank,
-                                                            int32_t *__restrict__ ids, u32 *__restrict__ keep,
-                                                            u64 *__restrict__ totals)
+// provisional vertex ids (int32, from mc_emit) -> final ids through `rank`, drop triangles with fewer than
+// three distinct indices (order kept), widen to int64 like np.unique's inverse.
+__global__ __launch_bounds__(256) void faces_rank_kernel(const int32_t *__restrict__ faces32, int64_t nf,
+                                                         const int32_t *__restrict__ rank, int32_t *__restrict__ ids,
+                                                         u32 *__restrict__ keep)
 {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nf) return;
-    int32_t id[3];
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        u32 p = find_vertex(fkey[3 * f + j], vkey, seg_voff, segs_per_row);
-        if (p == 0xffffffffu) { bad = true; id[j] = -1; }
-        else id[j] = rank ? rank[p] : (int32_t)p;
-    }
-    if (bad) atomicAdd(&totals[3], 1ull);
-    ids[3 * f + 0] = id[0]; ids[3 * f + 1] = id[1]; ids[3 * f + 2] = id[2];
-    keep[f] = (id[0] != id[1] && id[1] != id[2] && id[0] != id[2]) ? 1u : 0u;
+    int32_t a = rank[faces32[3 * f + 0]], b = rank[faces32[3 * f + 1]], c = rank[faces32[3 * f + 2]];
+    ids[3 * f + 0] = a; ids[3 * f + 1] = b; ids[3 * f + 2] = c;
+    keep[f] = (a != b && b != c && a != c) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void faces_compact_kernel(const int32_t *__restrict__ ids, const u32 *__restrict__ keep,
@@ -232,12 +208,10 @@ static FcLayout fc_layout(int64_t nf)
 
 TOMO_API int64_t tomo_mesh_faces_workspace_bytes(int64_t nf) { return (int64_t)fc_layout(nf).total; }
 
-TOMO_API int tomo_mesh_faces(const unsigned long long *fkey, int64_t nf, const unsigned long long *vkey, int64_t nv,
-                             const uint32_t *seg_voff, int Ny, int Nx, const int32_t *rank, int64_t *faces_out,
+TOMO_API int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                              unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    (void)Ny;
-    if (!fkey || !vkey || !seg_voff || !faces_out || !totals || !workspace || nf <= 0 || nv <= 0) return TOMO_E_ARG;
+    if (!faces32 || !rank || !faces_out || !totals || !workspace || nf <= 0) return TOMO_E_ARG;
     if (nf >= 0x7fffffffll) return TOMO_E_SIZE;
     FcLayout L = fc_layout(nf);
     if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
@@ -246,9 +220,7 @@ TOMO_API int tomo_mesh_faces(const unsigned long long *fkey, int64_t nf, const u
     u32 *keep = (u32 *)(ws + L.keep), *kscan = (u32 *)(ws + L.kscan);
     hipStream_t s = (hipStream_t)stream;
     unsigned blocks = (unsigned)ceil_div64(nf, 256);
-    int spr = (int)tomo_mc_segments_per_row(Nx);
-    hipLaunchKernelGGL(faces_resolve_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)fkey, nf, (const u64 *)vkey,
-                       seg_voff, spr, rank, ids, keep, (u64 *)totals);
+    hipLaunchKernelGGL(faces_rank_kernel, dim3(blocks), dim3(256), 0, s, faces32, nf, rank, ids, keep);
     size_t tb = L.temp_bytes;
     if (rocprim::inclusive_scan(ws + L.temp, tb, keep, kscan, (size_t)nf, rocprim::plus<u32>(), s) != hipSuccess)
         return TOMO_E_LAUNCH;

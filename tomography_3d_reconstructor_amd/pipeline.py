@@ -51,12 +51,9 @@ class Field:
 @dataclass
 class RawMesh:
     """Output of marching cubes before finalisation."""
-    vkey: torch.Tensor   # (V,) int64, ascending
-    vpos: torch.Tensor   # (V,3) float32 (z,y,x) as skimage returns them
-    fkey: torch.Tensor   # (F,3) int64 vertex keys, triangle order = reference order
-    seg_voff: torch.Tensor
-    Ny: int
-    Nx: int
+    vkey: torch.Tensor     # (V,) int64 vertex keys, ascending
+    vpos: torch.Tensor     # (V,3) float32 (z,y,x) as skimage returns them
+    faces32: torch.Tensor  # (F,3) int32 provisional vertex indices, triangle order = reference order
 
 
 # ----------------------------------------------------------------------------- binary stages
@@ -155,9 +152,11 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
 
 def field_from_dense(dense: torch.Tensor) -> Field:
     """Wrap an arbitrary float32 (Nz,Ny,Nx) device volume (tests: marching cubes on noise volumes)."""
-    dense = dense.contiguous().to(torch.float32)
     Nz, Ny, Nx = dense.shape
-    return Field(dense, Nz, Ny, Nx, Nx, 0)
+    pitch = (Nx + 3) // 4 * 4          # the marching-cubes loads read whole float4s inside a row's pitch
+    data = torch.zeros((Nz, Ny, pitch), dtype=torch.float32, device=dense.device)
+    data[:, :, :Nx] = dense
+    return Field(data, Nz, Ny, Nx, pitch, 0)
 
 
 # ----------------------------------------------------------------------------- marching cubes
@@ -171,30 +170,55 @@ def marching_cubes(f: Field, level: float = 0.5):
     if min(f.Nz, f.Ny, f.Nx) < 2:
         return None
     dev = f.data.device
-    spr = L.tomo_mc_segments_per_row(f.Nx)
+    st = _stream()
+    lvl = float(level)
+    geo = (f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, lvl)
+    spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
     nseg = f.Nz * f.Ny * spr
-    counts = torch.empty(nseg, dtype=torch.int32, device=dev)
-    _lib.check(L.tomo_mc_count(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), _p(counts), _stream()),
-               "tomo_mc_count")
-    seg_voff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-    seg_foff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-    active = torch.empty(nseg, dtype=torch.int32, device=dev)
-    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    # pass 1: active voxels per segment, scan, list of active segments
+    seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # zeroed by the call; 32-byte record per segment
+    _lib.check(L.tomo_mc_classify(_p(f.data), *geo, _p(seg_act), st), "tomo_mc_classify")
+    seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    active_segs = torch.empty(nseg, dtype=torch.int32, device=dev)
+    totals = torch.zeros(8, dtype=torch.int64, device=dev)
     wsb = L.tomo_mc_scan_workspace_bytes(nseg)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mc_scan(_p(counts), nseg, _p(seg_voff), _p(seg_foff), _p(active), _p(totals), _p(ws), wsb,
-                              _stream()), "tomo_mc_scan")
-    nv, nf, nact, _ = [int(x) for x in totals.cpu()]
+    _lib.check(L.tomo_mc_scan_segments(_p(seg_act), nseg, _p(seg_aoff), _p(active_segs), _p(totals), _p(ws), wsb, st),
+               "tomo_mc_scan_segments")
+    na, _, nas, _ = [int(x) for x in totals[:4].cpu()]
+    if na == 0:
+        return None
+    if na >= 2 ** 31:
+        raise _lib.TomoError("surface too large for 32-bit indices")
+    # pass 2-3: compact voxel list, one MC33 evaluation per active voxel, scan of the counts
+    vox_key = torch.empty(na, dtype=torch.int64, device=dev)
+    _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(active_segs), nas, _p(vox_key), st),
+               "tomo_mc_list")
+    del active_segs, seg_act
+    vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
+    vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")
+    vox_voff = torch.empty(na + 1, dtype=torch.int32, device=dev)
+    vox_foff = torch.empty(na + 1, dtype=torch.int32, device=dev)
+    tot2 = totals[4:]
+    wsb2 = L.tomo_mc_scan_workspace_bytes(na)
+    ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mc_scan(_p(vox_counts), na, _p(vox_voff), _p(vox_foff), None, _p(tot2), _p(ws2), wsb2, st),
+               "tomo_mc_scan")
+    nv, nf, _, _ = [int(x) for x in tot2.cpu()]
     if nv == 0:
         return None
     if nv >= 2 ** 31 or nf >= 2 ** 31:
         raise _lib.TomoError("mesh too large for 32-bit indices")
+    # pass 4: vertices and triangles
     vkey = torch.empty(nv, dtype=torch.int64, device=dev)
     vpos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
-    fkey = torch.empty((max(nf, 1), 3), dtype=torch.int64, device=dev)
-    _lib.check(L.tomo_mc_emit(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), _p(seg_voff), _p(seg_foff),
-                              _p(active), nact, _p(vkey), _p(vpos), _p(fkey), _stream()), "tomo_mc_emit")
-    return RawMesh(vkey, vpos, fkey[:nf], seg_voff, f.Ny, f.Nx)
+    faces32 = torch.empty((max(nf, 1), 3), dtype=torch.int32, device=dev)
+    _lib.check(L.tomo_mc_emit(_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_foff), _p(vox_flags),
+                              _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
+    mesh = RawMesh(vkey, vpos, faces32[:nf])
+    mesh._err = tot2   # tot2[3] != 0 would mean a triangle corner without vertex (checked after the next sync)
+    return mesh
 
 
 def finalize_vertices(vpos: torch.Tensor, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold=True, add_padding=True):
@@ -221,7 +245,7 @@ def ensure_manifold_mesh(mesh: RawMesh):
     remapped int64 faces without degenerate triangles.  mesh.vpos must already be finalised."""
     L = _lib.lib()
     dev = mesh.vpos.device
-    nv, nf = mesh.vpos.shape[0], mesh.fkey.shape[0]
+    nv, nf = mesh.vpos.shape[0], mesh.faces32.shape[0]
     totals = torch.zeros(4, dtype=torch.int64, device=dev)
     uniq = torch.empty((nv, 3), dtype=torch.float32, device=dev)
     rank = torch.empty(nv, dtype=torch.int32, device=dev)
@@ -234,11 +258,14 @@ def ensure_manifold_mesh(mesh: RawMesh):
         faces = torch.empty((nf, 3), dtype=torch.int64, device=dev)
         wsb2 = L.tomo_mesh_faces_workspace_bytes(nf)
         ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
-        _lib.check(L.tomo_mesh_faces(_p(mesh.fkey), nf, _p(mesh.vkey), nv, _p(mesh.seg_voff), mesh.Ny, mesh.Nx, _p(rank),
-                                     _p(faces), _p(totals), _p(ws2), wsb2, _stream()), "tomo_mesh_faces")
+        _lib.check(L.tomo_mesh_faces(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _p(ws2), wsb2, _stream()),
+                   "tomo_mesh_faces")
+    err = getattr(mesh, "_err", None)
+    if err is not None:
+        totals[3] = err[3]
     nu, nkeep, _, nbad = [int(x) for x in totals.cpu()]
     if nbad:
-        raise _lib.TomoError("internal error: %d face corners reference a missing vertex" % nbad)
+        raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % nbad)
     verts = uniq[:nu]
     faces = faces[:nkeep] if faces is not None else torch.empty((0, 3), dtype=torch.int64, device=dev)
     return verts, faces
