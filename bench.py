@@ -49,6 +49,7 @@ class FieldTimer:
 
     def __init__(self):
         self.pairs = []
+        self.padded_voxels = 0
         self.enabled = False
         self._orig = None
 
@@ -66,6 +67,8 @@ class FieldTimer:
             rc = timer._orig(*a)
             e1.record()
             timer.pairs.append((e0, e1))
+            nz, ny, nx, pad = a[2], a[3], a[4], a[5]
+            timer.padded_voxels = (nz + 2 * pad) * (ny + 2 * pad) * (nx + 2 * pad)
             return rc
 
         # ctypes function objects are attributes of the CDLL instance
@@ -119,14 +122,14 @@ def main():
     if dist:
         from tomography_3d_reconstructor_amd import slab
         gz = nz * world
-        job = slab.SlabJob(gz, ny, nx, rank, world, dev)
+        job = slab.SlabJob(gz, ny, nx, slab.TorchDistComm(dev))
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
         depths = np.full(gz, 1.0)
 
         def step():
             return job.run(mask, depths, 1.0, 1.0)
         total_voxels = gz * ny * nx
-        workload = "%dx%dx%d ellipsoid stack, Z-slabs of %d slices over %d GPUs" % (nx, ny, gz, nz, world)
+        workload = "%dx%dx%d ellipsoid stack, Z-slabs of %d slices over %d GPUs (halos over RCCL)" % (nx, ny, gz, nz, world)
         parallelism = "zslab%d" % world
     else:
         mask = pipeline.ellipsoid_mask(nz, ny, nx, dev).view(torch.uint8)
@@ -162,24 +165,31 @@ def main():
 
     ms = dt / max(args.steps, 1) * 1e3
     value = total_voxels * args.steps / dt / 1e6
-    Np = (nz + 2) * (ny + 2) * (nx + 2) if not dist else None
     fms = timer.mean_ms()
     roofline = None
     if fms:
-        if dist:
-            Np = timer_np  # noqa: F821  (set by slab path)
-        alg = 5.0 * Np
+        alg = 5.0 * timer.padded_voxels              # 1 B mask + 4 B field per padded voxel of the launch (rank 0)
         ach = alg / (fms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc.json")
+        if not dist and os.path.exists(pmc) and (nz, ny, nx) == (1024, 1024, 1024):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]   # separate rocprofv3 --pmc passes of this command
         roofline = {"bound": "hbm", "kernel": "field_gauss_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes": alg, "kernel_ms": round(fms, 4)}
+    nverts = int(res[0].shape[0]) if res else 0
+    nfaces = int(res[1].shape[0]) if res else 0
+    if dist:
+        cnt = torch.tensor([nverts, nfaces], dtype=torch.int64, device=dev)
+        td.all_reduce(cnt)
+        nverts, nfaces = [int(x) for x in cnt.cpu()]
     out = {
         "metric": "Mvoxels/s (SDF+MC) on 1024^3 ellipsoid stack; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "parallelism": parallelism, "inputs": "uint8 mask stack resident in HBM",
-                   "n_vertices": int(res[0].shape[0]) if res else 0, "n_faces": int(res[1].shape[0]) if res else 0},
+                   "n_vertices": nverts, "n_faces": nfaces},
         "roofline": roofline,
     }
     if rank == 0:

@@ -68,6 +68,9 @@ int tomo_fill_holes_slice(uint64_t *bits, int nz, int ny, int nx, int z, uint64_
  * workspace: tomo_close_ends_workspace_words() uint64 words. */
 int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);
 int tomo_close_ends_scan(uint64_t *bits, int nz, int ny, int nx, uint64_t *workspace, void *stream);
+/* The same chain reduced to a pair of bit planes gp_out = [G | P] (2 * ny * wx words) over slices 1 .. nz-2:
+ * c'[nz-2] = G | (P & c'[0]).  What a Z-slab rank publishes in the multi-GPU path (same workspace size). */
+int tomo_close_ends_gp(const uint64_t *bits, int nz, int ny, int nx, uint64_t *workspace, uint64_t *gp_out, void *stream);
 /* One 6-neighbour pass (skimage binary_erosion/binary_dilation, voxel_processor.py:88,91):
  * op 0 = erosion with border_value 1, op 1 = dilation with border value 0.  in != out. */
 int tomo_morph_pass(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, int op, void *stream);
@@ -117,10 +120,11 @@ int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int 
 /* 4. emit: vertices (key + raw MC position, (z,y,x) float32 as skimage returns them; keys ascending) and
  * triangles as provisional vertex indices (int32), in the reference's order and with the per-triangle
  * reversal of skimage/measure/_marching_cubes_lewiner.py:338.  totals[3] counts corners whose vertex was
- * not found (must stay 0). */
+ * not found (must stay 0).  z_offset (0 on one GPU) is added to the slice index of every vertex position before
+ * rounding: a Z-slab rank emits positions in global padded coordinates. */
 int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
                  const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff, const uint32_t *vox_voff,
-                 const uint32_t *vox_foff, const uint8_t *vox_flags, unsigned long long *vkey, float *vpos,
+                 const uint32_t *vox_foff, const uint8_t *vox_flags, int z_offset, unsigned long long *vkey, float *vpos,
                  int32_t *faces, unsigned long long *totals, void *stream);
 
 /* ---------------------------------------------------------------- mesh finalisation */

@@ -42,6 +42,11 @@ def lib():
                                          ctypes.c_double, ctypes.POINTER(ctypes.POINTER(ctypes.c_float)),
                                          ctypes.POINTER(ctypes.POINTER(ctypes.c_int)),
                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        L.orc_marching_cubes_zoff.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.POINTER(ctypes.c_float)),
+                                              ctypes.POINTER(ctypes.POINTER(ctypes.c_int)),
+                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.orc_free.argtypes = [ctypes.c_void_p]
         L.orc_finalize_vertices.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
@@ -98,7 +103,7 @@ def field(vol, manifold=True, add_padding=True):
     return out
 
 
-def marching_cubes(vol_f32, level=0.5):
+def marching_cubes(vol_f32, level=0.5, z_offset=0):
     """skimage.measure.marching_cubes(volume, level) -> (verts (V,3) f32 zyx, faces (F,3) i32).
 
     Raises ValueError / RuntimeError in the situations the wrapper does
@@ -116,8 +121,8 @@ def marching_cubes(vol_f32, level=0.5):
     pf = ctypes.POINTER(ctypes.c_int)()
     nv = ctypes.c_int64()
     nf = ctypes.c_int64()
-    rc = lib().orc_marching_cubes(_f32(v), v.shape[0], v.shape[1], v.shape[2], level,
-                                  ctypes.byref(pv), ctypes.byref(pf), ctypes.byref(nv), ctypes.byref(nf))
+    rc = lib().orc_marching_cubes_zoff(_f32(v), v.shape[0], v.shape[1], v.shape[2], level, int(z_offset),
+                                       ctypes.byref(pv), ctypes.byref(pf), ctypes.byref(nv), ctypes.byref(nf))
     if rc:
         raise MemoryError
     try:

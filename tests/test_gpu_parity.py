@@ -310,6 +310,47 @@ def test_mesh_properties_and_determinism_256(dev):
     assert len(vn) - len(e) // 2 + len(fn) == 2                      # V - E + F = 2
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_ranks_on_one_gpu_match_single_gpu(dev, world):
+    """The multi-GPU (Z-slab) path with the HIP engine: `world` rank threads share this GPU and talk through the
+    in-process communicator; the concatenated result must be byte-identical to the single-GPU mesh."""
+    import threading
+    from tomography_3d_reconstructor_amd import slab
+    nz, ny, nx = 96, 80, 112
+    rng = np.random.default_rng(3)
+    v = np.stack(O.ellipsoid_masks(nz, ny, nx))
+    v ^= rng.random(v.shape) < 0.01
+    v[0, 5:60, 7:90] = True
+    v[0, 20:30, 30:50] = False
+    v[nz // 2 - 1:nz // 2 + 1, ny // 2] = rng.random((2, nx)) < 0.5
+    depths = np.concatenate([np.full(16, 0.5), np.full(64, 0.25), np.full(16, 0.5)])
+    vol = pipeline.smooth(pipeline.close_ends(to_vol(v, dev)), 3, True)
+    rv, rf = pipeline.extract_surface(vol, depths, 0.7, 0.9)
+    out, errs = [None] * world, []
+
+    def target(c):
+        try:
+            job = slab.SlabJob(nz, ny, nx, c)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                mask = torch.from_numpy(v[job.z0:job.z1].astype(np.uint8)).to(dev)
+                verts, faces = job.run(mask, depths, 0.7, 0.9)
+                torch.cuda.current_stream().synchronize()
+            out[c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.vertex_offset, job.n_vertices_global)
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            raise
+
+    ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    verts = np.concatenate([o[0] for o in out])
+    faces = np.concatenate([o[1] for o in out])
+    assert out[0][3] == rv.shape[0]
+    assert verts.tobytes() == rv.cpu().numpy().tobytes()
+    assert np.array_equal(faces, rf.cpu().numpy())
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", None)
     monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libtomo_hip.so")

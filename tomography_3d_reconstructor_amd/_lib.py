@@ -38,6 +38,7 @@ SIGNATURES = {
     "tomo_fill_holes_slice": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_close_ends_workspace_words": (_c_i64, [_c_i, _c_i, _c_i]),
     "tomo_close_ends_scan": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "tomo_close_ends_gp": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
     "tomo_morph_pass": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_extend_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_field_fill": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
@@ -47,8 +48,8 @@ SIGNATURES = {
     "tomo_mc_scan": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mc_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "tomo_mc_eval": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p]),
-    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
-                            _c_p, _c_p, _c_p]),
+    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p,
+                            _c_p, _c_p, _c_p, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_unique": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

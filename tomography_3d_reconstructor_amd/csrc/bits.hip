@@ -363,6 +363,37 @@ TOMO_API int tomo_close_ends_scan(uint64_t *bits, int nz, int ny, int nx, uint64
     return tomo_status();
 }
 
+// (G, P) of the whole chain over slices 1 .. nz-2: composition of the per-chunk pairs.  This is what a Z-slab
+// rank publishes to the other ranks (multi-GPU close-ends): c'[nz-2] = G | (P & c'[0]).
+__global__ __launch_bounds__(256) void close_compose_kernel(const u64 *__restrict__ GP, u64 *__restrict__ out,
+                                                            int64_t slice_words, int nchunks)
+{
+    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= slice_words) return;
+    u64 G = 0, P = ~0ull;
+    for (int k = 0; k < nchunks; k++) {
+        u64 Gk = GP[((int64_t)k * 2) * slice_words + col], Pk = GP[((int64_t)k * 2 + 1) * slice_words + col];
+        G = Gk | (Pk & G);
+        P = Pk & P;
+    }
+    out[col] = G;
+    out[slice_words + col] = P;
+}
+
+TOMO_API int tomo_close_ends_gp(const uint64_t *bits, int nz, int ny, int nx, uint64_t *workspace, uint64_t *gp_out,
+                                void *stream)
+{
+    if (!bits || !workspace || !gp_out || nz < 3 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    int64_t sw = (int64_t)ny * tomo_words_per_row(nx);
+    int nchunks = (nz - 2 + CE_CHUNK - 1) / CE_CHUNK;
+    u64 *GP = (u64 *)workspace;
+    dim3 grid((unsigned)ceil_div64(sw, 256), (unsigned)nchunks);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(close_reduce_kernel, grid, dim3(256), 0, s, (const u64 *)bits, GP, nz, sw, nchunks);
+    hipLaunchKernelGGL(close_compose_kernel, dim3(grid.x), dim3(256), 0, s, (const u64 *)GP, (u64 *)gp_out, sw, nchunks);
+    return tomo_status();
+}
+
 // ------------------------------------------------------------------------------------------
 // 6-neighbour erosion (outside = 1) / dilation (outside = 0), one thread per word.
 template <int OP>

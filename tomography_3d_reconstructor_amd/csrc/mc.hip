@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
                                                       const u64 *__restrict__ vox_key, int64_t na,
                                                       const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
                                                       const u32 *__restrict__ vox_foff, const uint8_t *__restrict__ vox_flags,
-                                                      u64 *__restrict__ vkey, float *__restrict__ vpos,
+                                                      int z_offset, u64 *__restrict__ vkey, float *__restrict__ vpos,
                                                       int32_t *__restrict__ faces, u64 *__restrict__ totals)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
     load_cell(field, g, key, c);
     const int flags = vox_flags[i];
     u32 vo = vox_voff[i];
-    const float fZ = (float)c.Z, fY = (float)c.Y, fX = (float)c.X;
+    const int Zg = c.Z + z_offset;   // slab offset: positions are produced in global padded coordinates
+    const float fZ = (float)Zg, fY = (float)c.Y, fX = (float)c.X;
     if (flags & 1) {
         vkey[vo] = key | 0ull;
         float *p = vpos + 3 * (int64_t)vo;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
     if (flags & 4) {
         vkey[vo] = key | 2ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = (float)((double)c.Z + mc_edge_offset(c.v[0], c.v[4])); p[1] = fY; p[2] = fX;
+        p[0] = (float)((double)Zg + mc_edge_offset(c.v[0], c.v[4])); p[1] = fY; p[2] = fX;
         vo++;
     }
     if (flags & 8) {
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
         mc_centre_offset(c.v, &ox, &oy, &oz);
         vkey[vo] = key | 3ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = (float)((double)c.Z + oz); p[1] = (float)((double)c.Y + oy); p[2] = (float)((double)c.X + ox);
+        p[0] = (float)((double)Zg + oz); p[1] = (float)((double)c.Y + oy); p[2] = (float)((double)c.X + ox);
         vo++;
     }
     if (!(c.cell_ok && c.index != 0 && c.index != 255)) return;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
 
 TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
                           const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
-                          const uint32_t *vox_voff, const uint32_t *vox_foff, const uint8_t *vox_flags,
+                          const uint32_t *vox_voff, const uint32_t *vox_foff, const uint8_t *vox_flags, int z_offset,
                           unsigned long long *vkey, float *vpos, int32_t *faces, unsigned long long *totals, void *stream)
 {
     McGrid g;
@@ -571,7 +572,7 @@ TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pi
     int64_t blocks = ceil_div64(na, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
-                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_foff, vox_flags, (u64 *)vkey, vpos, faces,
+                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_foff, vox_flags, z_offset, (u64 *)vkey, vpos, faces,
                        (u64 *)totals);
     return tomo_status();
 }

@@ -160,7 +160,7 @@ def field_from_dense(dense: torch.Tensor) -> Field:
 
 
 # ----------------------------------------------------------------------------- marching cubes
-def marching_cubes(f: Field, level: float = 0.5):
+def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     """skimage.measure.marching_cubes(volume, level) (surface_extractor.py:55) -> RawMesh or None.
 
     None stands for the two exceptions of the wrapper that the reference swallows
@@ -215,7 +215,7 @@ def marching_cubes(f: Field, level: float = 0.5):
     vpos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
     faces32 = torch.empty((max(nf, 1), 3), dtype=torch.int32, device=dev)
     _lib.check(L.tomo_mc_emit(_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_foff), _p(vox_flags),
-                              _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
+                              int(z_offset), _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
     mesh = RawMesh(vkey, vpos, faces32[:nf])
     mesh._err = tot2   # tot2[3] != 0 would mean a triangle corner without vertex (checked after the next sync)
     return mesh

@@ -1,0 +1,354 @@
+"""Z-slab sharding of the hot path across the GPUs of one node (one process per GPU).
+
+The reference is single-process; this is the scale-out of the SAME path: the volume is
+cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, all with the z-neighbours
+(RCCL send/recv over xGMI) plus one tiny all-gather:
+
+  close ends   per-column carry chain c'[z] = c[z] | (c[z+1] & c'[z-1]): every rank reduces its slab to a
+               (G, P) pair of bit planes, the pairs are all-gathered (2 x ny*nx bits per rank) and folded into
+               each rank's carry-in; the first slice of rank r+1 is the one extra input slice.
+  smoothing    8 passes of a radius-1 stencil + 2 slices for the Gaussian: one exchange of 10 bit-packed halo
+               slices per side, after which every pass runs locally (the contaminated rim shrinks into the halo).
+  field        computed locally on the halo-extended slab; the owned field slices are exact.
+  marching     needs field slice z1 of rank r+1: THE one-slice float32 halo.
+  cubes
+  mesh         vertices on the shared plane are owned by the upper rank: rank r sends the coordinates of its
+               top-plane vertices up, gets their indices back, and an all-gather of the per-rank unique counts
+               gives the global numbering.  Faces stay on their rank, in reference order.
+
+The result is bit-identical to the single-GPU path (tests/test_slab_cpu.py with the CPU oracle as engine over
+gloo, tests/test_gpu_parity.py::test_slab_two_ranks_one_gpu with the HIP engine).
+
+The class is written against two small interfaces so that the same orchestration code runs on RCCL, on gloo
+(CPU tests) and inside one process (two threads sharing one GPU):
+  comm   : rank, world, send(t, dst), recv(src), all_gather(t)
+  engine : the device operations (HIP kernels in production; tests may inject the CPU oracle)
+"""
+import numpy as np
+import torch
+
+from . import pipeline
+
+HALO_BITS = 10   # 8 morphology passes + 2 slices for the 5-tap Gaussian along z
+
+
+# ----------------------------------------------------------------------------- communication
+class TorchDistComm:
+    """torch.distributed point-to-point + all_gather (backend "nccl" == RCCL on ROCm, or gloo on CPU)."""
+
+    def __init__(self, device):
+        import torch.distributed as td
+        self.td = td
+        self.rank = td.get_rank()
+        self.world = td.get_world_size()
+        self.device = device
+
+    def send(self, t, dst):
+        t = t.contiguous()
+        hdr = torch.tensor([t.dim()] + list(t.shape) + [0] * (7 - t.dim()), dtype=torch.int64, device=self.device)
+        self.td.send(hdr, dst)
+        if t.numel():
+            self.td.send(t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1), dst)
+
+    def recv(self, src, dtype):
+        hdr = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.td.recv(hdr, src)
+        h = hdr.cpu().tolist()
+        shape = h[1:1 + h[0]]
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        if out.numel():
+            buf = out.view(torch.uint8).reshape(-1) if dtype != torch.uint8 else out.reshape(-1)
+            self.td.recv(buf, src)
+        return out
+
+    def exchange(self, to_prev, to_next, dtype):
+        """Neighbour exchange along z.  `to_prev` goes to rank-1, `to_next` to rank+1; a direction is either used
+        by EVERY rank (all pass a tensor; the end ranks' tensor simply has no destination) or by none (all pass
+        None).  Returns (from_prev, from_next), None where there is no such neighbour / direction.
+        Even ranks send first, odd ranks receive first: no deadlock with blocking send/recv."""
+        r, w = self.rank, self.world
+        from_prev = from_next = None
+        for phase in (0, 1):
+            if (r % 2) == phase:
+                if r + 1 < w and to_next is not None:
+                    self.send(to_next, r + 1)
+                if r - 1 >= 0 and to_prev is not None:
+                    self.send(to_prev, r - 1)
+            else:
+                if r - 1 >= 0 and to_next is not None:
+                    from_prev = self.recv(r - 1, dtype)
+                if r + 1 < w and to_prev is not None:
+                    from_next = self.recv(r + 1, dtype)
+        return from_prev, from_next
+
+    def all_gather(self, t):
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t.contiguous())
+        return out
+
+
+class ThreadComm:
+    """In-process communicator for tests: `world` threads, queues between them (same call surface)."""
+
+    def __init__(self, rank, world, queues, barrier, gather_slots):
+        self.rank, self.world = rank, world
+        self.q, self.barrier, self.slots = queues, barrier, gather_slots
+
+    def send(self, t, dst):
+        self.q[(self.rank, dst)].put(t.clone())
+
+    def recv(self, src, dtype):
+        return self.q[(src, self.rank)].get(timeout=120)
+
+    def exchange(self, to_prev, to_next, dtype):
+        r, w = self.rank, self.world
+        if r + 1 < w and to_next is not None:
+            self.send(to_next, r + 1)
+        if r - 1 >= 0 and to_prev is not None:
+            self.send(to_prev, r - 1)
+        from_prev = self.recv(r - 1, dtype) if (r - 1 >= 0 and to_next is not None) else None
+        from_next = self.recv(r + 1, dtype) if (r + 1 < w and to_prev is not None) else None
+        return from_prev, from_next
+
+    def all_gather(self, t):
+        self.slots[self.rank] = t.clone()
+        self.barrier.wait()
+        out = [self.slots[i] for i in range(self.world)]
+        self.barrier.wait()
+        return out
+
+    @staticmethod
+    def make(world):
+        import queue
+        import threading
+        qs = {(a, b): queue.Queue() for a in range(world) for b in range(world) if a != b}
+        bar = threading.Barrier(world)
+        slots = [None] * world
+        return [ThreadComm(r, world, qs, bar, slots) for r in range(world)]
+
+
+# ----------------------------------------------------------------------------- the HIP engine
+class HipEngine:
+    """Device operations of the slab job, on BitVolume / torch tensors (libtomo_hip.so kernels)."""
+
+    def pack(self, mask):
+        return pipeline.pack(mask)
+
+    def bits(self, vol):
+        return vol.bits
+
+    def from_bits(self, bits, shape):
+        return pipeline.BitVolume(bits.contiguous(), tuple(shape))
+
+    def fill_holes(self, vol, z):
+        from . import _lib
+        nz, ny, nx = vol.shape
+        scratch = torch.empty(ny * vol.bits.shape[2] + 8, dtype=torch.int64, device=vol.bits.device)
+        _lib.check(_lib.lib().tomo_fill_holes_slice(vol.bits.data_ptr(), nz, ny, nx, z, scratch.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "tomo_fill_holes_slice")
+
+    def close_gp(self, vol):
+        """(G, P) bit planes of the carry chain over slices 1 .. nz-2 of `vol` (nz >= 3)."""
+        from . import _lib
+        L = _lib.lib()
+        nz, ny, nx = vol.shape
+        wx = vol.bits.shape[2]
+        ws = torch.empty(L.tomo_close_ends_workspace_words(nz, ny, nx), dtype=torch.int64, device=vol.bits.device)
+        gp = torch.empty((2, ny, wx), dtype=torch.int64, device=vol.bits.device)
+        _lib.check(L.tomo_close_ends_gp(vol.bits.data_ptr(), nz, ny, nx, ws.data_ptr(), gp.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "tomo_close_ends_gp")
+        return gp[0], gp[1]
+
+    def close_scan(self, vol):
+        from . import _lib
+        L = _lib.lib()
+        nz, ny, nx = vol.shape
+        if nz > 2:
+            ws = torch.empty(L.tomo_close_ends_workspace_words(nz, ny, nx), dtype=torch.int64, device=vol.bits.device)
+            _lib.check(L.tomo_close_ends_scan(vol.bits.data_ptr(), nz, ny, nx, ws.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "tomo_close_ends_scan")
+
+    def popcount(self, vol):
+        return int(pipeline.popcount_async(vol).item())
+
+    def smooth(self, vol, iterations, create_manifold):
+        return pipeline.smooth(vol, iterations, create_manifold)
+
+    def field(self, vol):
+        return pipeline.make_field(vol, True, True)
+
+    def field_slices(self, f, a, b):
+        return pipeline.Field(f.data[a:b], b - a, f.Ny, f.Nx, f.pitch, f.xorg)
+
+    def field_set_slice(self, f, z, slice_data):
+        f.data[z].copy_(slice_data.reshape(f.data.shape[1], f.data.shape[2]))
+
+    def marching_cubes(self, f, z_offset):
+        return pipeline.marching_cubes(f, 0.5, z_offset)
+
+    def finalize_vertices(self, vpos, depths, mm_y, mm_x):
+        return pipeline.finalize_vertices(vpos, depths, mm_y, mm_x, True, True)
+
+    def unique(self, vpos):
+        """-> (uniq (U,3), rank (V,) int32 final index of every input row)."""
+        from . import _lib
+        L = _lib.lib()
+        dev = vpos.device
+        nv = vpos.shape[0]
+        totals = torch.zeros(4, dtype=torch.int64, device=dev)
+        uniq = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        rank = torch.empty(nv, dtype=torch.int32, device=dev)
+        wsb = L.tomo_mesh_unique_workspace_bytes(nv)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.check(L.tomo_mesh_unique(vpos.contiguous().data_ptr(), nv, uniq.data_ptr(), rank.data_ptr(), totals.data_ptr(),
+                                      ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream), "tomo_mesh_unique")
+        return uniq[: int(totals[0].item())], rank
+
+
+# ----------------------------------------------------------------------------- the job
+def slab_range(gz, rank, world):
+    base, rem = divmod(gz, world)
+    z0 = rank * base + min(rank, rem)
+    return z0, z0 + base + (1 if rank < rem else 0)
+
+
+def _fold_words(a, b, op):
+    return op(a, b)
+
+
+class SlabJob:
+    """One rank's share of: close ends -> smooth -> field -> marching cubes -> global mesh numbering."""
+
+    def __init__(self, gz, ny, nx, comm, engine=None, iterations=3, create_manifold=True, close_ends=True):
+        self.gz, self.ny, self.nx = gz, ny, nx
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.world
+        self.z0, self.z1 = slab_range(gz, self.rank, self.world)
+        self.eng = engine or HipEngine()
+        self.iterations, self.create_manifold, self.close_ends = iterations, create_manifold, close_ends
+        self.halo = 2 * (self.iterations + (1 if create_manifold else 0)) + 2
+        if self.z1 - self.z0 < self.halo + 1 and self.world > 1:
+            raise ValueError("slab thinner than the halo (%d slices): use fewer ranks" % self.halo)
+        self.active = None
+
+    # -- step 1: closed slab (bits tensor of the owned slices)
+    def _close_ends(self, vol):
+        e, c = self.eng, self.comm
+        first, last = self.rank == 0, self.rank == self.world - 1
+        nzl = self.z1 - self.z0
+        if first:
+            e.fill_holes(vol, 0)
+        if last:
+            e.fill_holes(vol, nzl - 1)
+        bits = e.bits(vol)
+        if self.world == 1:
+            e.close_scan(vol)
+            return e.bits(vol)
+        # the original first slice of the next rank is the extra input of the chain
+        _, nxt = c.exchange(bits[:1], None, torch.int64)
+        parts = ([] if first else [torch.zeros_like(bits[:1])]) + [bits] + ([] if last else [nxt])
+        ext = e.from_bits(torch.cat(parts, 0), (nzl + len(parts) - 1, self.ny, self.nx))
+        G, P = e.close_gp(ext)
+        gathered = c.all_gather(torch.stack([G, P, bits[0]], 0))
+        carry = gathered[0][2]                                      # c'[0] = (filled) global slice 0
+        for q in range(self.rank):                                  # fold the lower ranks' (G, P)
+            carry = gathered[q][0] | (gathered[q][1] & carry)
+        xb = e.bits(ext)
+        if not first:
+            xb[0] = carry
+        e.close_scan(ext)
+        xb = e.bits(ext)
+        return xb[(0 if first else 1):(0 if first else 1) + nzl]
+
+    # -- the whole pass
+    def run(self, mask, slice_depths, mm_y, mm_x):
+        """mask: this rank's slices (nzl, ny, nx) uint8/bool on the device.  Returns (vertices, faces) of THIS
+        rank: its unique vertices (globally sorted across ranks) and its faces with GLOBAL vertex indices, plus
+        sets self.vertex_offset / self.n_vertices_global."""
+        e, c = self.eng, self.comm
+        first, last = self.rank == 0, self.rank == self.world - 1
+        nzl = self.z1 - self.z0
+        vol = e.pack(mask)
+        bits = self._close_ends(vol) if self.close_ends else e.bits(vol)
+        closed = e.from_bits(bits, (nzl, self.ny, self.nx))
+        # halo for morphology + Gaussian
+        H = self.halo
+        if self.world > 1:
+            lo, hi = c.exchange(bits[:H], bits[nzl - H:], torch.int64)
+            parts = ([] if first else [lo]) + [bits] + ([] if last else [hi])
+            ext = e.from_bits(torch.cat(parts, 0), (nzl + (0 if first else H) + (0 if last else H), self.ny, self.nx))
+        else:
+            ext = closed
+        sm = e.smooth(ext, self.iterations, self.create_manifold)
+        # keep 2 halo slices for the field
+        sb = e.bits(sm)
+        a = 0 if first else H - 2
+        b = sb.shape[0] - (0 if last else H - 2)
+        fvol = e.from_bits(sb[a:b], (b - a, self.ny, self.nx))
+        f = e.field(fvol)
+        # owned padded slices: local field index range [fa, fb); local slice fb (computed without its upper
+        # neighbourhood, hence wrong) is replaced by THE one-slice field halo: the first owned slice of rank+1
+        fa = 0 if first else 3
+        fb = f.Nz - (0 if last else 3)
+        if self.world > 1:
+            _, top = c.exchange(e.field_slices(f, fa, fa + 1).data, None, torch.float32)
+            if not last:
+                e.field_set_slice(f, fb, top)
+        f = e.field_slices(f, fa, fb + (0 if last else 1))
+        Za = 0 if first else self.z0 + 1            # global padded index of the first owned slice
+        mesh = e.marching_cubes(f, Za)
+        dev = mask.device
+        if mesh is None:
+            vpos = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+            faces32 = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+        else:
+            vpos, faces32 = mesh.vpos, mesh.faces32
+            e.finalize_vertices(vpos, slice_depths, mm_y, mm_x)
+        return self._global_numbering(vpos, faces32, slice_depths, dev)
+
+    # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
+    def _global_numbering(self, vpos, faces32, slice_depths, dev):
+        e, c = self.eng, self.comm
+        first, last = self.rank == 0, self.rank == self.world - 1
+        nv = vpos.shape[0]
+        if self.world == 1:
+            uniq, rank = (e.unique(vpos) if nv else (vpos, torch.zeros(0, dtype=torch.int32, device=dev)))
+            faces = self._faces(faces32, rank.to(torch.int64))
+            self.vertex_offset, self.n_vertices_global = 0, uniq.shape[0]
+            return uniq, faces
+        # mapped z of the shared plane Zb = z1 + 1 (padded) through the same finalisation arithmetic
+        if not last:
+            zb = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
+            zb = float(e.finalize_vertices(zb, slice_depths, 1.0, 1.0)[0, 0].item())
+            top = (vpos[:, 0] == zb) if nv else torch.zeros(0, dtype=torch.bool, device=dev)
+        else:
+            top = torch.zeros(nv, dtype=torch.bool, device=dev)
+        top_idx = torch.nonzero(top).reshape(-1)
+        keep_idx = torch.nonzero(~top).reshape(-1)
+        from_prev, _ = c.exchange(None, vpos[top_idx].contiguous(), torch.float32)
+        own = vpos[keep_idx]
+        n_own = own.shape[0]
+        allv = torch.cat([own, from_prev.reshape(-1, 3)], 0) if from_prev is not None else own
+        if allv.shape[0]:
+            uniq, rank = e.unique(allv.contiguous())
+        else:
+            uniq, rank = allv, torch.zeros(0, dtype=torch.int32, device=dev)
+        # indices of the lower neighbour's top-plane vertices go back down
+        _, ids_next = c.exchange(rank[n_own:].contiguous(), None, torch.int32)
+        counts = c.all_gather(torch.tensor([uniq.shape[0]], dtype=torch.int64, device=dev))
+        counts = [int(x.item()) for x in counts]
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        self.vertex_offset, self.n_vertices_global = int(offs[self.rank]), int(offs[-1])
+        gid = torch.empty(nv, dtype=torch.int64, device=dev)
+        gid[keep_idx] = rank[:n_own].to(torch.int64) + int(offs[self.rank])
+        if not last and top_idx.numel():
+            gid[top_idx] = ids_next.to(torch.int64) + int(offs[self.rank + 1])
+        return uniq, self._faces(faces32, gid)
+
+    @staticmethod
+    def _faces(faces32, gid):
+        if faces32.shape[0] == 0:
+            return torch.zeros((0, 3), dtype=torch.int64, device=faces32.device)
+        f = gid[faces32.to(torch.int64)]
+        keep = (f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])
+        return f[keep]
