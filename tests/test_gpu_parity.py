@@ -125,6 +125,50 @@ def test_field_vs_oracle(dev, shape, pad):
     assert got.tobytes() == exp.tobytes()
 
 
+@pytest.mark.parametrize("shape", [(6, 40, 2100), (5, 12, 4200), (4, 9, 4096), (3, 7, 8200)])
+def test_field_wide_rows_vs_oracle(dev, shape):
+    """rows wider than one 256-thread block (576 / 1024 threads) and wider than one block (multi-block rows)"""
+    rng = np.random.default_rng(shape[2])
+    v = rng.random(shape) < 0.5
+    v[:, :, 1000:1900] = True          # a constant stretch: const-wave path next to general waves
+    v[:, :, 2500:3000] = False
+    for pad in (True, False):
+        f = pipeline.make_field(to_vol(v, dev), True, pad)
+        assert f.dense().cpu().numpy().tobytes() == O.field(v, True, pad).tobytes()
+
+
+def test_whole_path_wide_noise_vs_oracle(dev):
+    rng = np.random.default_rng(21)
+    v = rng.random((14, 30, 2300)) < 0.45
+    v[:, 10:20, 500:1500] = True
+    depths = np.linspace(0.2, 0.9, 14)
+    vol = pipeline.smooth(pipeline.close_ends(to_vol(v, dev)), 2, True)
+    osm = O.smooth(O.close_ends(v), 2, True)
+    assert np.array_equal(to_np(vol), osm)
+    got = pipeline.extract_surface(vol, depths, 0.3, 1.7)
+    ev, ef = O.SurfaceExtractor().extract_manifold_surface(osm, depths, 0.3, 1.7)
+    assert got[0].cpu().numpy().tobytes() == ev.tobytes() and np.array_equal(got[1].cpu().numpy(), ef)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2), (2, 3, 5), (3, 2, 70), (1, 9, 9), (9, 1, 9), (9, 9, 1), (5, 5, 257)])
+@pytest.mark.parametrize("pad", [True, False])
+def test_whole_path_tiny_and_degenerate_shapes(dev, shape, pad):
+    rng = np.random.default_rng(sum(shape))
+    v = rng.random(shape) < 0.6
+    depths = np.full(shape[0], 0.5)
+    vol = to_vol(v, dev)
+    got = pipeline.extract_surface(vol, depths, 1.0, 2.0, True, pad)
+    exp = O.SurfaceExtractor().extract_manifold_surface(v, depths, 1.0, 2.0, True, True, pad)
+    if exp is None:
+        assert got is None
+    else:
+        assert got is not None
+        ev, ef = exp
+        gf = got[1].cpu().numpy()
+        assert got[0].cpu().numpy().tobytes() == ev.tobytes()
+        assert (gf.shape[0] == 0 and len(ef) == 0) or np.array_equal(gf, ef)
+
+
 def test_field_uniform_fast_paths(dev):
     # all-ones interior, all-zero exterior and a sharp boundary in one volume
     v = np.zeros((40, 70, 600), bool)
