@@ -212,6 +212,17 @@ def test_mc_matches_oracle_on_wide_noise(dev):
     assert tri.tobytes() == ev[ef].tobytes() and len(vpos) == len(ev)
 
 
+def test_first_touch_numbering_on_noise(dev):
+    """manifold=False: skimage's own vertex numbering (first touch in the serial scan), all MC33 cases"""
+    d = np.load(os.path.join(G, "mc_noise.npz"))
+    for name in ("uniform", "lattice", "binfield"):
+        vol = d[name + "_vol"]
+        mesh = pipeline.marching_cubes(pipeline.field_from_dense(torch.from_numpy(vol).to(dev)), 0.5)
+        v, f = pipeline.first_touch_order(mesh)
+        assert v.cpu().numpy().tobytes() == d[name + "_verts"].tobytes()
+        assert np.array_equal(f.cpu().numpy(), d[name + "_faces"])
+
+
 def test_mc_none_cases(dev):
     z = torch.zeros((4, 5, 6), device=dev)
     assert pipeline.marching_cubes(pipeline.field_from_dense(z), 0.5) is None
@@ -220,8 +231,8 @@ def test_mc_none_cases(dev):
 
 
 # ------------------------------------------------------------------ whole path
-CASES = ["a_blobs", "b_noise", "c_noise_nomanifold_smooth", "d_nopad", "f_noclose", "g_empty", "h_full", "i_noise_raw",
-         "j_wide"]
+CASES = ["a_blobs", "b_noise", "c_noise_nomanifold_smooth", "d_nopad", "e_nomanifold", "f_noclose", "g_empty", "h_full",
+         "i_noise_raw", "j_wide"]
 
 
 def load_case(cn):
@@ -252,7 +263,7 @@ def test_pipeline_small_golden(dev, cn, capsys):
         assert res is None
         return
     v, f = res
-    assert v.dtype == np.float32 and f.dtype == np.int64 and v.flags.c_contiguous
+    assert v.dtype == np.float32 and str(f.dtype) == str(c["faces_dtype"]) and v.flags.c_contiguous
     assert v.shape == c["verts"].shape and f.shape == c["faces"].shape
     assert np.array_equal(f, c["faces"])
     assert v.tobytes() == c["verts"].tobytes()

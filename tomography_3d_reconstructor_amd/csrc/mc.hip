@@ -576,3 +576,75 @@ TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pi
                        (u64 *)totals);
     return tomo_status();
 }
+
+// ------------------------------------------------------------------------------------------ first touch
+// manifold=False exposes skimage's vertex NUMBERING: vertices are numbered in the order the serial z->y->x
+// scan first touches them (cell order, then order of first appearance in the cell's triangle list).  Every
+// existing cell around a bichromatic edge references it, so the vertex on an edge is created by the
+// scan-minimal cell around it: for an x edge with owner voxel (ox,oy,oz) that is cell (ox, oy-1|oy, oz-1|oz)
+// taking the lower index where it exists; likewise for y and z edges; a centre vertex by its own cell.
+// mode 0: created[i] = number of vertices cell i creates;  mode 1: ft_rank[provisional id] = base[i] + j.
+__global__ __launch_bounds__(256) void mc_first_touch_kernel(const float *__restrict__ field, const McGrid g,
+                                                             const u64 *__restrict__ vox_key, int64_t na,
+                                                             const u32 *__restrict__ seg_aoff,
+                                                             const u32 *__restrict__ vox_voff,
+                                                             const uint8_t *__restrict__ vox_flags, int mode,
+                                                             u32 *__restrict__ created, const u32 *__restrict__ base,
+                                                             int32_t *__restrict__ ft_rank, u64 *__restrict__ totals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    Cell c;
+    load_cell(field, g, vox_key[i], c);
+    u32 n = 0;
+    if (c.cell_ok && c.index != 0 && c.index != 255) {
+        McTiling t = mc_cell_tiling(c.v, c.index);
+        const int flags = vox_flags[i];
+        u32 seen = 0;
+        const int64_t rowY = (int64_t)g.Ny;
+        for (int k = 0; k < 3 * t.ntri; k++) {
+            int ed = t.tris[k];
+            if (seen & (1u << ed)) continue;
+            seen |= 1u << ed;
+            int dx = (ed == 1 || ed == 5 || ed == 9 || ed == 10) ? 1 : 0;
+            int dy = (ed == 2 || ed == 6 || ed == 10 || ed == 11) ? 1 : 0;
+            int dz = (ed >= 4 && ed <= 7) ? 1 : 0;
+            int slot = ed == 12 ? 3 : (ed >= 8 ? 2 : (ed & 1));
+            int ox = c.X + dx, oy = c.Y + dy, oz = c.Z + dz;
+            bool creator;
+            if (slot == 0) creator = (dy == (oy > 0 ? 1 : 0)) && (dz == (oz > 0 ? 1 : 0));
+            else if (slot == 1) creator = (dx == (ox > 0 ? 1 : 0)) && (dz == (oz > 0 ? 1 : 0));
+            else if (slot == 2) creator = (dx == (ox > 0 ? 1 : 0)) && (dy == (oy > 0 ? 1 : 0));
+            else creator = true;
+            if (!creator) continue;
+            if (mode == 1) {
+                u32 v;
+                if ((dx | dy | dz) == 0) v = (flags & (1 << slot)) ? vox_voff[i] + (u32)__popc(flags & ((1 << slot) - 1)) : 0xffffffffu;
+                else v = find_vertex(make_key(c.row + dy + dz * rowY, ox, 0), slot, g, vox_key, seg_aoff, vox_voff, vox_flags);
+                if (v == 0xffffffffu) atomicAdd(&totals[3], 1ull);
+                else ft_rank[v] = (int32_t)(base[i] + n);
+            }
+            n++;
+        }
+    }
+    if (mode == 0) created[i] = n;
+}
+
+TOMO_API int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                                 const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
+                                 const uint32_t *vox_voff, const uint8_t *vox_flags, int mode, uint32_t *created,
+                                 const uint32_t *base, int32_t *ft_rank, unsigned long long *totals, void *stream)
+{
+    McGrid g;
+    int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
+    if (rc) return rc;
+    if (!vox_key || !seg_aoff || !vox_voff || !vox_flags || !totals || (mode == 0 && !created) ||
+        (mode == 1 && (!base || !ft_rank)) || (mode != 0 && mode != 1))
+        return TOMO_E_ARG;
+    if (na <= 0) return TOMO_OK;
+    int64_t blocks = ceil_div64(na, 256);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc_first_touch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
+                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_flags, mode, created, base, ft_rank, (u64 *)totals);
+    return tomo_status();
+}

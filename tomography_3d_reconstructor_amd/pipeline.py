@@ -217,6 +217,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     _lib.check(L.tomo_mc_emit(_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_foff), _p(vox_flags),
                               int(z_offset), _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
     mesh = RawMesh(vkey, vpos, faces32[:nf])
+    mesh._mc = (f, geo, vox_key, na, seg_aoff, vox_voff, vox_flags)   # for first_touch_order (manifold=False)
     mesh._err = tot2   # tot2[3] != 0 would mean a triangle corner without vertex (checked after the next sync)
     return mesh
 
@@ -271,19 +272,51 @@ def ensure_manifold_mesh(mesh: RawMesh):
     return verts, faces
 
 
+def first_touch_order(mesh: RawMesh):
+    """Renumber a RawMesh the way skimage numbers vertices (order of first touch in the serial cell scan).
+    Returns (vpos (V,3) float32, faces (F,3) int32): what measure.marching_cubes returns to the reference."""
+    L = _lib.lib()
+    f, geo, vox_key, na, seg_aoff, vox_voff, vox_flags = mesh._mc
+    dev = mesh.vpos.device
+    st = _stream()
+    nv = mesh.vpos.shape[0]
+    created = torch.empty(na, dtype=torch.int32, device=dev)
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    args = (_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_flags))
+    _lib.check(L.tomo_mc_first_touch(*args, 0, _p(created), None, None, _p(totals), st), "tomo_mc_first_touch")
+    base = torch.empty(na + 1, dtype=torch.int32, device=dev)
+    wsb = L.tomo_mc_scan_workspace_bytes(na)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mc_scan(_p(created), na, _p(base), None, None, _p(totals), _p(ws), wsb, st), "tomo_mc_scan")
+    ft_rank = torch.full((nv,), -1, dtype=torch.int32, device=dev)
+    _lib.check(L.tomo_mc_first_touch(*args, 1, None, _p(base), _p(ft_rank), _p(totals), st), "tomo_mc_first_touch")
+    ncreated, _, _, nbad = [int(x) for x in totals.cpu()]
+    if nbad or ncreated != nv or int((ft_rank < 0).sum().item()):
+        raise _lib.TomoError("internal error: first-touch numbering is not a permutation of the vertices")
+    idx = ft_rank.to(torch.int64)
+    vpos = torch.empty_like(mesh.vpos)
+    vpos[idx] = mesh.vpos
+    faces = ft_rank[mesh.faces32.to(torch.int64)] if mesh.faces32.shape[0] else mesh.faces32
+    return vpos, faces
+
+
 def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold=True, add_padding=True):
     """extract_manifold_surface (surface_extractor.py:34-75) on device tensors.
 
-    Returns (vertices (V,3) float32, faces (F,3) int64) device tensors, or None where the reference
-    returns None.
+    Returns (vertices (V,3) float32, faces (F,3) int64 -- int32 and skimage's numbering when manifold=False)
+    device tensors, or None where the reference returns None.
     """
-    if not manifold:
-        raise NotImplementedError("manifold=False (first-touch vertex numbering) is not built yet")
     f = make_field(vol, manifold, add_padding)
     mesh = marching_cubes(f, 0.5)
-    del f
     if mesh is None:
         return None
+    if not manifold:
+        # surface_extractor.py:55-72 without the manifold branches: skimage's own numbering, int32 faces
+        vpos, faces = first_touch_order(mesh)
+        finalize_vertices(vpos, slice_depths, mm_per_pixel_y, mm_per_pixel_x, False, add_padding)
+        return vpos, faces
+    mesh._mc = None
+    del f
     finalize_vertices(mesh.vpos, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
     return ensure_manifold_mesh(mesh)
 
