@@ -53,7 +53,7 @@ int64_t tomo_ext_slices(int nz, int pad);                /* nz + 2 pad + 4 */
 /* Field buffer: float32 (Nz, Ny, pitch); padded column X lives at column tomo_field_xorg + X. */
 int64_t tomo_field_pitch(int nx, int pad);
 int tomo_field_xorg(int pad);                            /* 32 - pad: data column x = 0 sits on a 128-byte line */
-int64_t tomo_mc_segments_per_row(int Nx, int xorg);      /* ceil((xorg + Nx) / 256) */
+int64_t tomo_mc_segments_per_row(int Nx, int xorg);      /* ceil((xorg + Nx + 224) / 256) */
 
 /* ---------------------------------------------------------------- binary stages */
 /* np.stack(mask_images) as uint8 0/1 (voxel_processor.py:46) -> bits. */
@@ -82,22 +82,38 @@ int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx
  * gaussian_filter(sigma=0.5) (three 5-tap float64 correlate1d passes, axis 0,1,2, mode reflect),
  * cast to float32.  gaussian = 0 writes the raw 0/1 field (manifold=False). */
 int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
-                    void *stream);
+                    unsigned long long *signs, void *stream);
+/* Sign records (input of marching-cubes pass 1): uint64 [Nz][S][NyP][4], S = tomo_mc_segments_per_row(Nx, xorg),
+ * NyP = tomo_sign_rows(Ny) (Ny rounded up to 16 so that 16-row groups of records are 512-byte aligned);
+ * bit L of word k of record (Z, s, Y) = [field(Z, Y, column 256 s - 224 + 4 L + k) > iso].  tomo_field_fill writes
+ * them as a by-product (iso 0.5) when `signs` is not NULL, gaussian = 1 and tomo_field_signs_fused(nx) is 1 -- the
+ * caller must have ZEROED the buffer (records of all-zero regions are not written);
+ * tomo_field_signs derives them from any float field for slices [z_begin, z_end). */
+int64_t tomo_sign_rows(int Ny);
+int tomo_field_signs_fused(int nx);
+/* Size (uint64 words) of the buffer passed as `signs` to tomo_field_fill / tomo_field_signs_finish: the records
+ * followed by per-chunk flags.  The field kernel writes final records for its constant waves and leaves the sign
+ * bits of the other waves lane-major in the record area; tomo_field_signs_finish (to be called right after
+ * tomo_field_fill) converts those chunks in place (~1 KB each). */
+int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg);
+int tomo_field_signs_finish(const float *field, int nz, int ny, int nx, int pad, unsigned long long *signs, void *stream);
+int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso, int z_begin,
+                     int z_end, unsigned long long *signs, void *stream);
 
 /* ---------------------------------------------------------------- marching cubes (Lewiner MC33) */
 /* skimage.measure.marching_cubes(volume, level) (surface_extractor.py:55) as five device passes.
- * A SEGMENT = 256 consecutive float columns of a field row (voxel X is in segment (X + xorg) / 256);
+ * A SEGMENT = 256 consecutive float columns of a field row (voxel X is in segment (X + xorg + 224) / 256);
  * nseg = Nz * Ny * tomo_mc_segments_per_row(Nx, xorg).
  * A voxel is ACTIVE when its 8 cube corners (neighbours clamped at the volume border) are not all on one side
  * of `iso` (a corner equal to iso counts as below, like the reference).
  * vertex/voxel key = (row << 22) | (X << 2) | slot, row = Z*Ny + Y; slot 0/1/2 = x/y/z edge owned by the
  * voxel, 3 = cell-centre vertex (voxel keys have slot 0).
  *
- * 1. classify (the only full-volume pass): for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose
- *    bit L says voxel 4L+k of the segment (X = 256 s + 4L + k - xorg) is active; the call first zeroes the
- *    whole array (seg_act: uint64[4*nseg]) so empty segments read as 0. */
-int tomo_mc_classify(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                     unsigned long long *seg_act, void *stream);
+ * 1. classify: from the sign records, for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose bit L
+ *    says voxel 4L+k of the segment (X = 256 s - 224 + 4L + k - xorg) is active; the call first zeroes the whole
+ *    array (seg_act: uint64[4*nseg], seg = (Z*Ny + Y)*S + s) so empty segments read as 0.  No float is read. */
+int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg, unsigned long long *seg_act,
+                     void *stream);
 /* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of the per-segment active-voxel counts
  * (popcount of the seg_act record), active_segs uint32[nseg] = indices of the non-empty segments in order,
  * totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */

@@ -42,14 +42,14 @@ def test_geometry_helpers():
             pitch = L.tomo_field_pitch(nx, pad)
             assert pitch % 32 == 0 and pitch >= L.tomo_field_xorg(pad) + nx + 2 * pad
             assert L.tomo_ext_words_per_row(nx, pad) * 64 >= nx + pad + 6 + 4
-    assert L.tomo_mc_segments_per_row(1026, 31) == 5 and L.tomo_mc_segments_per_row(256, 0) == 1
+    assert L.tomo_mc_segments_per_row(1026, 31) == 6 and L.tomo_mc_segments_per_row(32, 0) == 1
 
 
 def test_argument_checks_do_not_need_a_gpu():
     L = _lib.lib()
     assert L.tomo_pack_bits(None, None, 1, 1, 1, None) == -1
     assert L.tomo_morph_pass(None, None, 4, 4, 4, 0, None) == -1
-    assert L.tomo_mc_classify(None, 4, 4, 4, 4, 0, 0.5, None, None) == -1
+    assert L.tomo_mc_classify(None, 4, 4, 4, 0, None, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

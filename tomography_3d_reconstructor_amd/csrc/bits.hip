@@ -21,8 +21,10 @@ TOMO_API int64_t tomo_field_pitch(int nx, int pad)
     int64_t cols = (int64_t)(32 - pad) + nx + 2 * pad;
     return (cols + 31) / 32 * 32;
 }
-// marching-cubes segments are 256 float COLUMNS of a field row (16-byte aligned lane loads)
-TOMO_API int64_t tomo_mc_segments_per_row(int Nx, int xorg) { return ((int64_t)Nx + xorg + 255) / 256; }
+// marching-cubes segments are 256 float COLUMNS of a field row, segment s = columns [256 s - 224, 256 s + 32)
+// rows per (slice, segment) block of sign records: Ny rounded up so that 16-row groups are 512-byte aligned
+TOMO_API int64_t tomo_sign_rows(int Ny) { return ((int64_t)Ny + 15) / 16 * 16; }
+TOMO_API int64_t tomo_mc_segments_per_row(int Nx, int xorg) { return ((int64_t)Nx + xorg + SEG_SHIFT + 255) / 256; }
 
 // ------------------------------------------------------------------------------------------
 // pack: one wave per group of 16 words (1024 voxels) of a row; lane L reads the byte of voxel

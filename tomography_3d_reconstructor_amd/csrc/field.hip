@@ -37,6 +37,11 @@ struct FieldParams {
     int r;                  // nx % 4
     int rows_per_block;
     int W;                  // 32-bit ext words staged per row and block
+    u64 *signs;             // sign records [Z][S][NyP][4] (may be null)
+    int S;                  // marching-cubes segments per row
+    int NyP;                // rows per (Z, segment) block of records: Ny rounded up to 16
+    u32 *sflags;            // per (Z, segment, row chunk): 1 = records final, 0 = lane-major words to convert
+    const float *fieldp;    // (convert kernel) the field, to read the right pad column
 };
 
 __device__ static inline double tap5(double a, double b, double c, double d, double e)
@@ -75,6 +80,29 @@ __device__ static inline void store_pad_columns(float *obase, const FieldParams 
         if (w_first) o[p.xorg] = s_pad[0][lane];
         if (w_last) o[p.xorg + p.Nx - 1] = s_pad[1][lane];
     }
+}
+
+// Sign records of the two segments that hold only a pad column: segment 0 (column 31 = X 0 is its lane 63,
+// element 3) and, when the right pad column starts a new segment, segment wave + 2 (its lane 0, element 0).
+__device__ static inline void store_pad_signs(const FieldParams &p, float (*s_pad)[32], bool left, bool right, int Z,
+                                              int wave, int Y0, int nrows_out, int lane)
+{
+    if (lane >= nrows_out) return;
+    if (left) {
+        ulonglong2 *o = (ulonglong2 *)(p.signs + ((((int64_t)Z * p.S + 0) * p.NyP) + Y0 + lane) * 4);
+        o[0] = make_ulonglong2(0ull, 0ull);
+        o[1] = make_ulonglong2(0ull, s_pad[0][lane] > 0.5f ? (1ull << 63) : 0ull);
+    }
+    if (right && wave + 2 < p.S) {
+        ulonglong2 *o = (ulonglong2 *)(p.signs + ((((int64_t)Z * p.S + wave + 2) * p.NyP) + Y0 + lane) * 4);
+        o[0] = make_ulonglong2(s_pad[1][lane] > 0.5f ? 1ull : 0ull, 0ull);
+        o[1] = make_ulonglong2(0ull, 0ull);
+    }
+}
+
+__device__ static inline float p_field_pad(const FieldParams &p, int Z, int Y)
+{
+    return p.fieldp[((int64_t)Z * p.Ny + Y) * p.pitch + p.xorg + p.Nx - 1];
 }
 
 template <int MAXT>
@@ -171,6 +199,11 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         wconst = allz ? 1 : (allo ? 2 : 0);
     }
     float *const obase = field + ((int64_t)Z * p.Ny + Y0) * p.pitch;
+    // sign records (marching-cubes pass 1 input): wave w of a single-block row is exactly MC segment w + 1
+    const bool do_signs = p.signs != nullptr && !multi;
+    u64 *const srec = do_signs ? p.signs + ((((int64_t)Z * p.S + (wave + 1)) * p.NyP) + Y0) * 4 : nullptr;
+    const int padlane = p.nq - t0w;                 // lane whose element 0 is the right pad column (when nx % 4 == 0)
+    if (do_signs && lane == 0) p.sflags[((int64_t)Z * p.S + (wave + 1)) * gridDim.y + blockIdx.y] = wconst ? 1u : 0u;
     if (wconst) {   // publish the (constant) pass-2 halo values for both row parities, once
         const double k2 = wconst == 1 ? 0.0 : c2;
         if (lane < 8) s_halo[lane >> 2][wave][lane & 3] = k2;
@@ -193,6 +226,14 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         if (p.pad && (w_first || w_last)) {                        // pad columns: their bits are zero => wconst == 1
             if (lane < 32) { if (w_first) s_pad[0][lane] = 0.0f; if (w_last) s_pad[1][lane] = 0.0f; }
             store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
+        }
+        if (do_signs) {
+            if (wconst == 2)                               // all-zero waves: the caller zeroed the buffer
+                for (int j = 0; j < Y1 - Y0; j += 16) {    // 16 rows x 32 B = one 512-byte store
+                    int nr = Y1 - Y0 - j < 16 ? Y1 - Y0 - j : 16;
+                    if (lane < 4 * nr) srec[(int64_t)j * 4 + lane] = ~0ull;
+                }
+            store_pad_signs(p, s_pad, w_first, w_last && padlane == 64, Z, wave, Y0, Y1 - Y0, lane);
         }
         return;
     }
@@ -270,6 +311,15 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
             o2 = (float)tap5(q0, q1, q2, q3, R0);                                                      \
             o3 = (float)tap5(q1, q2, q3, R0, R1);                                                      \
         }                                                                                              \
+        if (do_signs) {   /* 4 sign bits of this lane and row; 8 rows per word, stored lane-major (256 B per wave) */ \
+            u32 n4 = ((u32)(0x3F000000 - __float_as_int(o0)) >> 31) | (((u32)(0x3F000000 - __float_as_int(o1f)) >> 31) << 1) | \
+                     (((u32)(0x3F000000 - __float_as_int(o2)) >> 31) << 2) | (((u32)(0x3F000000 - __float_as_int(o3)) >> 31) << 3); \
+            nibacc |= n4 << (((Y - Y0) & 7) * 4);                                                      \
+            if (((Y - Y0) & 7) == 7 || Y == Y1 - 1) {                                                  \
+                ((u32 *)srec)[(int64_t)((Y - Y0) >> 3) * 64 + lane] = nibacc;                          \
+                nibacc = 0;                                                                            \
+            }                                                                                          \
+        }                                                                                              \
         if (full4) {                                                                                   \
             *(float4 *)(orow + col0) = make_float4(o0, o1f, o2, o3);                                     \
         } else if (can_out) {                                                                          \
@@ -285,6 +335,9 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         orow += p.pitch;                                                                               \
     }
 
+    // sign bits of this lane: 4 per row, 8 rows per register, parked in LDS per 8 rows and turned into records
+    // after the row loop (keeps ballots / SGPR pressure out of the hot loop)
+    u32 nibacc = 0;
     float *orow = obase;
     int Y = Y0;
     while (Y < Y1) {
@@ -294,11 +347,58 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         STEP(wd, we, wa, wb, wc, cd, ce, ca, cb, cc); if (++Y >= Y1) break;
         STEP(we, wa, wb, wc, wd, ce, ca, cb, cc, cd); ++Y;
     }
-    if (p.pad && (w_first || w_last)) store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
+    if (p.pad && (w_first || w_last)) {
+        store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
+        if (do_signs) store_pad_signs(p, s_pad, w_first, w_last && padlane == 64, Z, wave, Y0, Y1 - Y0, lane);
+    }
 #undef STEP
 #undef LOOKUP
 #undef CODES
 #undef SPREAD
+}
+
+// The non-constant waves of the field kernel leave their sign bits LANE-MAJOR in the record area (one 32-bit word
+// per lane and 8 rows: bit 4r+k = element k of row r); this turns them into the ballot records the classify pass
+// reads (bit L of word k of row r), in place.  One wave per flagged (Z, segment, chunk of rows): ~1 KB each.
+__global__ __launch_bounds__(256) void field_signs_convert_kernel(FieldParams p, int nchunks, int nwaves, int64_t ntasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (Z, wave, chunk), chunk fastest
+    if (task >= ntasks) return;
+    const int chunk = (int)(task % nchunks);
+    const int64_t tz = task / nchunks;
+    const int wave = (int)(tz % nwaves), s = wave + 1;
+    const int Z = (int)(tz / nwaves);
+    if (p.sflags[((int64_t)Z * p.S + s) * nchunks + chunk] != 0u) return;
+    const int Y0 = chunk * p.rows_per_block;
+    const int nr = (Y0 + p.rows_per_block < p.Ny ? p.rows_per_block : p.Ny - Y0);
+    u64 *srec = p.signs + ((((int64_t)Z * p.S + s) * p.NyP) + Y0) * 4;
+    u32 w[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) w[g] = (g * 8 < nr) ? ((const u32 *)srec)[g * 64 + lane] : 0u;
+    // right pad column = element 0 of lane `padlane` of the last wave: its value was computed separately
+    const int t0w = wave * 64, padlane = p.nq - t0w;
+    const bool patch = p.pad && p.r == 0 && padlane >= 0 && padlane < 64;
+    u64 rec = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int r = g * 8 + rr;
+            u32 n4 = (w[g] >> (rr * 4)) & 15u;
+            if (patch && lane == padlane && r < nr) {
+                float pv = p_field_pad(p, Z, Y0 + r);
+                n4 = (n4 & ~1u) | (pv > 0.5f ? 1u : 0u);
+            }
+            u64 b0 = __ballot(n4 & 1u), b1 = __ballot(n4 & 2u), b2 = __ballot(n4 & 4u), b3 = __ballot(n4 & 8u);
+            const int r16 = r & 15;
+            if ((lane >> 2) == r16) rec = (lane & 3) == 0 ? b0 : ((lane & 3) == 1 ? b1 : ((lane & 3) == 2 ? b2 : b3));
+            if (r < nr && (r16 == 15 || r == nr - 1)) {
+                if (lane < 4 * (r16 + 1)) srec[(int64_t)(r - r16) * 4 + lane] = rec;
+            }
+        }
+    }
+    if (lane == 0) p.sflags[((int64_t)Z * p.S + s) * nchunks + chunk] = 1u;   // converted: a second call is a no-op
 }
 
 // manifold=False: the field is the raw 0/1 volume (surface_extractor.py:46 without the Gaussian).
@@ -316,11 +416,8 @@ __global__ __launch_bounds__(256) void field_raw_kernel(const u64 *__restrict__ 
     field[((int64_t)Z * Ny + Y) * pitch + xorg + X] = (float)((w >> (e & 63)) & 1ull);
 }
 
-TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
-                             void *stream)
+static void fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs)
 {
-    if (!ext || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
-    FieldParams p;
     p.nz = nz; p.ny = ny; p.nx = nx; p.pad = pad;
     p.Nz = nz + 2 * pad; p.Ny = ny + 2 * pad; p.Nx = nx + 2 * pad;
     p.EY = (int)tomo_ext_rows(ny, pad);
@@ -330,8 +427,56 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
     p.nq = (nx + 3) / 4;
     p.r = nx % 4;
     p.nlanes = p.nq + (p.r ? 1 : 0);
-    p.rows_per_block = 32;
-    p.W = 0;
+    int threads = (p.nlanes + 63) / 64 * 64;
+    if (threads > 1024) threads = 1024;
+    p.rows_per_block = threads <= 256 ? 32 : 16;
+    p.W = (4 * threads + 4 + 31) / 32 + 1;
+    if (p.W > p.EWX32) p.W = p.EWX32;
+    p.S = (int)tomo_mc_segments_per_row(p.Nx, p.xorg);
+    p.NyP = (int)tomo_sign_rows(p.Ny);
+    p.signs = (u64 *)signs;
+    p.fieldp = nullptr;
+    p.sflags = signs ? (u32 *)((u64 *)signs + (int64_t)p.Nz * p.S * p.NyP * 4) : nullptr;
+}
+
+TOMO_API int tomo_field_signs_fused(int nx)
+{   // does tomo_field_fill(gaussian = 1) write the sign records itself for this row width?  (one block per row)
+    int nq = (nx + 3) / 4, nlanes = nq + ((nx % 4) ? 1 : 0);
+    return (nlanes + 63) / 64 * 64 <= 1024 ? 1 : 0;
+}
+
+TOMO_API int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg)
+{   // uint64 words: the sign records [Nz][S][NyP][4] followed by the field kernel's per-chunk flags
+    int64_t S = tomo_mc_segments_per_row(Nx, xorg), NyP = tomo_sign_rows(Ny);
+    int64_t chunks = (Ny + 15) / 16;
+    return (int64_t)Nz * S * NyP * 4 + ((int64_t)Nz * S * chunks + 1) / 2 + 8;
+}
+
+// Second step of the fused sign records: convert the lane-major words of the non-constant waves (see the kernel).
+TOMO_API int tomo_field_signs_finish(const float *field, int nz, int ny, int nx, int pad, unsigned long long *signs,
+                                     void *stream)
+{
+    if (!field || !signs || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
+    if (!tomo_field_signs_fused(nx)) return TOMO_E_ARG;
+    FieldParams p;
+    fill_params(p, nz, ny, nx, pad, signs);
+    p.fieldp = field;
+    int nchunks = (int)ceil_div64(p.Ny, p.rows_per_block);
+    int nwaves = (p.nlanes + 63) / 64;
+    int64_t ntasks = (int64_t)p.Nz * nwaves * nchunks;
+    int64_t blocks = ceil_div64(ntasks, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(field_signs_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, nchunks,
+                       nwaves, ntasks);
+    return tomo_status();
+}
+
+TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
+                             unsigned long long *signs, void *stream)
+{
+    if (!ext || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
+    FieldParams p;
+    fill_params(p, nz, ny, nx, pad, (gaussian && tomo_field_signs_fused(nx)) ? signs : nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (!gaussian) {
         int64_t total = (int64_t)p.Nz * p.Ny * p.Nx;
@@ -348,10 +493,6 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
         threads = 1024;
         gx = (unsigned)ceil_div64(p.nlanes, threads - 2);
     }
-    p.rows_per_block = threads <= 256 ? 32 : 16;
-    // staged words per row: ext bits [4*tstart + 2, 4*(tstart + threads) + 6) of a block
-    p.W = (4 * threads + 4 + 31) / 32 + 1;
-    if (p.W > p.EWX32) p.W = p.EWX32;
     size_t lds = ((size_t)5 * (p.rows_per_block + 4) * p.W + 10 * p.W) * sizeof(u32);
     dim3 grid(gx, (unsigned)ceil_div64(p.Ny, p.rows_per_block), (unsigned)p.Nz);
     if (threads <= 256)

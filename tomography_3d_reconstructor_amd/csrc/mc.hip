@@ -7,10 +7,11 @@
 //     (0/1/2 = x/y/z edge, 3 = cell-centre vertex).  An edge vertex exists iff the field changes side of
 //     the iso level along the edge (every MC33 tiling uses exactly the bichromatic edges of its cube);
 //     a centre vertex exists iff the cell's tiling row contains a 12;
-//   * pass 1 (the only full-volume pass, HBM-bound, 4 B/voxel): a wave owns a 256-voxel column SEGMENT
-//     and marches down y with the (y, z) / (y, z+1) rows of its 4 voxels per lane in registers, so each
-//     field value is loaded once per slice pair; it only counts the ACTIVE voxels (8 cube corners not all
-//     on one side) per (row, segment) with ballots -- no MC33 code in the streaming pass;
+//   * pass 1 never touches the float field: the field kernel leaves one SIGN BIT per voxel behind (32-byte
+//     records per row and 256-column segment), and the ACTIVE voxels (8 cube corners not all on one side)
+//     of a segment follow from the records of four rows with a few 64-bit operations per segment
+//     (1.25 bit/voxel of traffic instead of 4 B/voxel); fields that did not come from the field kernel
+//     get their sign records from field_signs_kernel;
 //   * scan -> offsets; pass 2 writes the compact, ordered list of active voxels (surface-sized);
 //   * pass 3 evaluates MC33 once per active voxel, ONE VOXEL PER LANE (full lane utilisation for the
 //     branchy code), giving triangle and vertex counts; scan -> output offsets;
@@ -26,8 +27,6 @@
 
 #define SEG 256
 #define KEY_XBITS 20
-#define CLS_R 8      // rows of cells per classify task
-#define CLS_ZC 16    // slices per classify task
 
 struct McGrid {
     int Nz, Ny, Nx;
@@ -44,153 +43,142 @@ __device__ static inline u64 make_key(int64_t row, int X, int slot)
     return ((u64)row << (KEY_XBITS + 2)) | ((u64)(u32)X << 2) | (u64)slot;
 }
 
-// Lane L of segment s looks at float columns 256 s + 4 L .. + 3 of a field row, i.e. padded voxels
-// X0 .. X0+3 with X0 = 256 s + 4 L - xorg (may start left of the row: voxels with X < 0 do not exist).
-// 5-bit "above iso" mask of X0..X0+4 of one row; values outside [0, Nx) are clamped to the row end (=> no
-// sign change across the border).  Bit 4 comes from the next lane except at the wave / row end.
-// All loads are unconditional and branch-free (a float4 from a clamped start column plus one scalar), so that
-// the compiler can keep every row of a step in flight at once; the clamping is undone on the compare bits.
-struct RowRaw { float4u v; float e; };
+// ------------------------------------------------------------------------------------------ pass 1
+// Sign records: for every (slice Z, segment s, row Y) four 64-bit words, bit L of word k = [field > iso] at
+// column 256 s - 224 + 4 L + k, laid out [Z][s][Y][4] (a wave's consecutive rows are consecutive records and a
+// Z-slab is a contiguous view).  The field ("SDF") kernel writes them as a by-product (field.hip); this generic
+// kernel derives them from any float field (dense test volumes, the halo slice of a Z-slab, very wide rows).
+__device__ static inline int64_t tomo_sign_rows_dev(int Ny) { return ((int64_t)Ny + 15) / 16 * 16; }
 
-__device__ static inline int clampx(int X, int Nx) { return X < 0 ? 0 : (X < Nx ? X : Nx - 1); }
-
-struct LaneGeom {
-    int Xs;        // start of the 4-float load: X0 clamped to [0, Nx-4]
-    int Xe;        // column of the 5th value (X0+4 clamped)
-    int i0, i1, i2, i3;   // which of the 4 loaded floats holds the value of voxel X0+k (clamped)
-    bool own_e;    // the 5th value comes from this lane's scalar load (wave / row end), else from the next lane
-};
-
-__device__ static inline LaneGeom lane_geom(int X0, int Nx, int lane)
+__global__ __launch_bounds__(256) void field_signs_kernel(const float *__restrict__ field, const McGrid g, int z_begin,
+                                                          int64_t ntasks, u64 *__restrict__ signs)
 {
-    LaneGeom q;
-    int hi = Nx - 4 > 0 ? Nx - 4 : 0;
-    q.Xs = X0 < 0 ? 0 : (X0 < hi ? X0 : hi);
-    q.Xe = clampx(X0 + 4, Nx);
-    q.i0 = clampx(X0, Nx) - q.Xs; q.i1 = clampx(X0 + 1, Nx) - q.Xs;
-    q.i2 = clampx(X0 + 2, Nx) - q.Xs; q.i3 = clampx(X0 + 3, Nx) - q.Xs;
-    q.own_e = (lane == 63) || (X0 + 4 >= Nx) || (X0 + 4 <= 0);
-    return q;
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (Z - z_begin, s, Y), Y fastest
+    if (task >= ntasks) return;
+    const int Y = (int)(task % g.Ny);
+    const int64_t tz = task / g.Ny;
+    const int s = (int)(tz % g.segs_per_row);
+    const int Z = z_begin + (int)(tz / g.segs_per_row);
+    const int X0 = s * SEG + lane * 4 - SEG_SHIFT - g.xorg;
+    const int64_t NyP = tomo_sign_rows_dev(g.Ny);
+    const float *row = field + ((int64_t)Z * g.Ny + Y) * g.pitch + g.xorg;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (X0 + k >= 0 && X0 + k < g.Nx) ? row[X0 + k] : 0.0f;
+    u64 b0 = __ballot((double)v[0] > g.iso), b1 = __ballot((double)v[1] > g.iso);
+    u64 b2 = __ballot((double)v[2] > g.iso), b3 = __ballot((double)v[3] > g.iso);
+    if (lane < 4)
+        signs[((((int64_t)Z * g.segs_per_row + s) * NyP) + Y) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
 }
 
-__device__ static inline RowRaw row_load(const float *__restrict__ row, const LaneGeom &q)
+// One LANE per (Z, s, Y): the active-voxel ballots of the segment from the sign records of the four rows
+// (Z,Y) (Z,Y+1) (Z+1,Y) (Z+1,Y+1) (neighbours clamped at the volume border) -- 64-bit logic only.
+// For every non-empty segment the four ballots go, as one aligned 32-byte record, into the zeroed seg_act.
+struct Rec4 { u64 b[4]; };
+
+__device__ static inline Rec4 load_rec(const u64 *__restrict__ signs, int64_t idx)
 {
-    RowRaw r;
-    r.v = *(const float4u *)(row + q.Xs);
-    r.e = row[q.Xe];
+    const ulonglong2 *q = (const ulonglong2 *)(signs + idx * 4);
+    ulonglong2 lo = q[0], hi = q[1];
+    Rec4 r; r.b[0] = lo.x; r.b[1] = lo.y; r.b[2] = hi.x; r.b[3] = hi.y;
     return r;
 }
 
-// 5-bit "above iso" mask of voxels X0..X0+4 (values outside the row are clamped to its ends)
-__device__ static inline u32 row_mask5(const RowRaw &r, const LaneGeom &q, double iso)
+__global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__restrict__ signs, const McGrid g,
+                                                               int64_t ntasks, u64 *__restrict__ seg_act)
 {
-    u32 c = ((double)r.v.x > iso ? 1u : 0u) | ((double)r.v.y > iso ? 2u : 0u) | ((double)r.v.z > iso ? 4u : 0u) |
-            ((double)r.v.w > iso ? 8u : 0u);
-    u32 m = ((c >> q.i0) & 1u) | (((c >> q.i1) & 1u) << 1) | (((c >> q.i2) & 1u) << 2) | (((c >> q.i3) & 1u) << 3);
-    u32 nxt = (u32)dpp_from_next((int)(m & 1u), 0);
-    u32 own = (double)r.e > iso ? 1u : 0u;
-    return m | ((q.own_e ? own : nxt) << 4);
-}
-
-// which of the lane's 4 voxels are active, from the masks of rows (Z,Y) (Z,Y+1) (Z+1,Y) (Z+1,Y+1)
-__device__ static inline u32 active_mask4(u32 ma, u32 mb, u32 mc, u32 md, u32 valid)
-{
-    u32 any = ma | mb | mc | md, all = ma & mb & mc & md;
-    return ((any | (any >> 1)) & ~(all & (all >> 1))) & valid;
-}
-
-__device__ static inline u32 valid_mask4(int X0, int Nx)
-{
-    u32 v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) v |= (X0 + k >= 0 && X0 + k < Nx) ? (1u << k) : 0u;
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------ pass 1
-// One wave = one task = (segment column s, group of CLS_R rows, chunk of CLS_ZC slices).  It marches along
-// z with the 5-bit masks of the CLS_R + 1 rows of the previous slice in registers, so a field value is
-// loaded (CLS_R+1)/CLS_R * (CLS_ZC+1)/CLS_ZC ~ 1.2 times instead of 4 (2 with row marching only).
-// For every non-empty (row, segment) it writes the four 64-bit ballots (bit L of ballot k = voxel 4L+k of the
-// segment is active) as one aligned 32-byte record into the zero-initialised seg_act array; empty segments are
-// not written at all (isolated 4-byte stores are very expensive on this memory system).
-__global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restrict__ field, const McGrid g, int ngroups,
-                                                          int nzc, int64_t ntasks, u64 *__restrict__ seg_act)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (Z, s, Y), Y fastest
     if (task >= ntasks) return;
-    const int s = (int)(task % g.segs_per_row);
-    const int64_t tc = task / g.segs_per_row;
-    const int grp = (int)(tc % ngroups);
-    const int zc = (int)(tc / ngroups);
-    const int Y0 = grp * CLS_R;
-    const int Zbeg = zc * CLS_ZC, Zend = Zbeg + CLS_ZC < g.Nz ? Zbeg + CLS_ZC : g.Nz;
-    const int X0 = s * SEG + lane * 4 - g.xorg;
-    const u32 valid = valid_mask4(X0, g.Nx);
-    const LaneGeom q = lane_geom(X0, g.Nx, lane);
-    const float *base = field + g.xorg;
-    int64_t yoff[CLS_R + 1];
+    const int Y = (int)(task % g.Ny);
+    const int64_t tz = task / g.Ny;
+    const int s = (int)(tz % g.segs_per_row);
+    const int Z = (int)(tz / g.segs_per_row);
+    const int S = g.segs_per_row;
+    const int Yn = Y + 1 < g.Ny ? Y + 1 : g.Ny - 1, Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
+    const int Xbase = s * SEG - SEG_SHIFT - g.xorg;      // X of (lane 0, k 0)
+    if (Xbase >= g.Nx || Xbase + SEG <= 0) return;       // no voxel of the row in this segment
+    const bool has_next = s + 1 < S;
+    const int64_t NyP = tomo_sign_rows_dev(g.Ny);
+    const int64_t ia = ((int64_t)Z * S + s) * NyP + Y, ib = ((int64_t)Z * S + s) * NyP + Yn;
+    const int64_t ic = ((int64_t)Z1 * S + s) * NyP + Y, id = ((int64_t)Z1 * S + s) * NyP + Yn;
+    Rec4 R[4] = {load_rec(signs, ia), load_rec(signs, ib), load_rec(signs, ic), load_rec(signs, id)};
+    u64 nx0[4];                                          // first column of the next segment, same rows
+    nx0[0] = has_next ? signs[(ia + NyP) * 4] & 1ull : 0ull;
+    nx0[1] = has_next ? signs[(ib + NyP) * 4] & 1ull : 0ull;
+    nx0[2] = has_next ? signs[(ic + NyP) * 4] & 1ull : 0ull;
+    nx0[3] = has_next ? signs[(id + NyP) * 4] & 1ull : 0ull;
+    // per element k: which lanes hold an existing voxel, and which lane holds the last voxel X = Nx-1 (its
+    // x+1 neighbour is clamped to itself)
+    u64 act[4];
+    u64 any_nonzero = 0;
 #pragma unroll
-    for (int r = 0; r <= CLS_R; r++) yoff[r] = (int64_t)(Y0 + r < g.Ny ? Y0 + r : g.Ny - 1) * g.pitch;
-    u32 m0[CLS_R + 1], m1[CLS_R + 1];
-    {
-        RowRaw raw[CLS_R + 1];
-        const float *sl = base + (int64_t)Zbeg * g.Ny * g.pitch;
+    for (int k = 0; k < 4; k++) {
+        // lanes L with 0 <= Xbase + 4L + k < Nx
+        int lo = Xbase + k < 0 ? (-(Xbase + k) + 3) / 4 : 0;
+        int hi = (g.Nx - 1 - Xbase - k) >= 0 ? (g.Nx - 1 - Xbase - k) / 4 : -1;      // last valid lane
+        if (hi > 63) hi = 63;
+        u64 vmask = 0;
+        if (hi >= lo) vmask = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+        int dl = g.Nx - 1 - Xbase - k;                                               // X == Nx-1 <=> 4L == dl
+        u64 lastm = (dl >= 0 && (dl & 3) == 0 && (dl >> 2) < 64) ? (1ull << (dl >> 2)) : 0ull;
+        u64 any = 0, all = ~0ull;
 #pragma unroll
-        for (int r = 0; r <= CLS_R; r++) raw[r] = row_load(sl + yoff[r], q);
-#pragma unroll
-        for (int r = 0; r <= CLS_R; r++) m0[r] = row_mask5(raw[r], q, g.iso);
+        for (int r = 0; r < 4; r++) {
+            u64 cur = R[r].b[k];
+            u64 nxt = k < 3 ? R[r].b[k + 1] : ((R[r].b[0] >> 1) | (nx0[r] << 63));
+            nxt = (nxt & ~lastm) | (cur & lastm);
+            any |= cur | nxt;
+            all &= cur & nxt;
+        }
+        act[k] = any & ~all & vmask;
+        any_nonzero |= act[k];
     }
-    for (int Z = Zbeg; Z < Zend; Z++) {
-        const int Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
-        {
-            RowRaw raw[CLS_R + 1];
-            const float *sl = base + (int64_t)Z1 * g.Ny * g.pitch;
-#pragma unroll
-            for (int r = 0; r <= CLS_R; r++) raw[r] = row_load(sl + yoff[r], q);
-#pragma unroll
-            for (int r = 0; r <= CLS_R; r++) m1[r] = row_mask5(raw[r], q, g.iso);
-        }
-#pragma unroll
-        for (int r = 0; r < CLS_R; r++) {
-            u32 act = active_mask4(m0[r], m0[r + 1], m1[r], m1[r + 1], valid);
-            u64 b0 = __ballot(act & 1u), b1 = __ballot(act & 2u), b2 = __ballot(act & 4u), b3 = __ballot(act & 8u);
-            // only non-empty segments are written (one aligned 32-byte record); the array was zeroed before
-            if ((b0 | b1 | b2 | b3) && Y0 + r < g.Ny && lane < 4) {
-                int64_t seg = ((int64_t)Z * g.Ny + Y0 + r) * g.segs_per_row + s;
-                seg_act[seg * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
-            }
-        }
-#pragma unroll
-        for (int r = 0; r <= CLS_R; r++) m0[r] = m1[r];
+    if (any_nonzero) {
+        ulonglong2 *o = (ulonglong2 *)(seg_act + (((int64_t)Z * g.Ny + Y) * S + s) * 4);
+        o[0] = make_ulonglong2(act[0], act[1]);
+        o[1] = make_ulonglong2(act[2], act[3]);
     }
 }
 
 static inline int make_grid(McGrid &g, const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso)
 {
     if (!field || Nz < 2 || Ny < 2 || Nx < 2 || pitch < Nx + xorg) return TOMO_E_ARG;
-    if (Nx >= (1 << KEY_XBITS) || Nz > 65535) return TOMO_E_SIZE;
+    if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
     g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = pitch; g.xorg = xorg; g.iso = iso;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
     return TOMO_OK;
 }
 
-TOMO_API int tomo_mc_classify(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                              unsigned long long *seg_act, void *stream)
+TOMO_API int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                              int z_begin, int z_end, unsigned long long *signs, void *stream)
 {
     McGrid g;
     int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
     if (rc) return rc;
-    if (!seg_act) return TOMO_E_ARG;
-    int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row;
-    if (hipMemsetAsync(seg_act, 0, (size_t)nseg * 32, (hipStream_t)stream) != hipSuccess) return TOMO_E_LAUNCH;
-    int ngroups = (Ny + CLS_R - 1) / CLS_R, nzc = (Nz + CLS_ZC - 1) / CLS_ZC;
-    int64_t ntasks = (int64_t)g.segs_per_row * ngroups * nzc;
+    if (!signs || z_begin < 0 || z_end > Nz || z_begin > z_end) return TOMO_E_ARG;
+    int64_t ntasks = (int64_t)(z_end - z_begin) * g.segs_per_row * Ny;
+    if (ntasks == 0) return TOMO_OK;
     int64_t blocks = ceil_div64(ntasks, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(mc_classify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g, ngroups,
-                       nzc, ntasks, (u64 *)seg_act);
+    hipLaunchKernelGGL(field_signs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g, z_begin,
+                       ntasks, (u64 *)signs);
+    return tomo_status();
+}
+
+TOMO_API int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg,
+                              unsigned long long *seg_act, void *stream)
+{
+    if (!signs || !seg_act || Nz < 2 || Ny < 2 || Nx < 2) return TOMO_E_ARG;
+    if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row;
+    if (hipMemsetAsync(seg_act, 0, (size_t)nseg * 32, (hipStream_t)stream) != hipSuccess) return TOMO_E_LAUNCH;
+    int64_t blocks = ceil_div64(nseg, 256);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc_classify_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const u64 *)signs, g, nseg, (u64 *)seg_act);
     return tomo_status();
 }
 
@@ -368,7 +356,7 @@ __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 
     ulonglong2 lo = q[0], hi = q[1];
     u64 b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
     u32 o = seg_aoff[seg];
-    const int Xs = s * SEG - g.xorg;
+    const int Xs = s * SEG - SEG_SHIFT - g.xorg;
     u64 any = b0 | b1 | b2 | b3;
     while (any) {                                   // lanes (groups of 4 voxels) that hold an active voxel, ascending
         int L = __ffsll((long long)any) - 1;
@@ -472,7 +460,7 @@ __device__ static inline u32 find_vertex(u64 okey, int slot, const McGrid &g, co
 {
     u64 row = okey >> (KEY_XBITS + 2);
     u32 X = (u32)(okey >> 2) & ((1u << KEY_XBITS) - 1u);
-    u64 seg = row * (u64)g.segs_per_row + ((X + (u32)g.xorg) >> 8);
+    u64 seg = row * (u64)g.segs_per_row + ((X + (u32)g.xorg + SEG_SHIFT) >> 8);
     u32 lo = seg_aoff[seg], end = seg_aoff[seg + 1], hi = end;
     while (lo < hi) {
         u32 mid = lo + ((hi - lo) >> 1);

@@ -6,6 +6,9 @@
 
 #define TOMO_API extern "C" __attribute__((visibility("default")))
 #define WAVE 64
+// Marching-cubes segment s = float columns [256 s - SEG_SHIFT, 256 s - SEG_SHIFT + 256) of a field row, so that
+// wave w of the field kernel (columns 32 + 256 w ...) is exactly segment w + 1.
+#define SEG_SHIFT 224
 
 typedef unsigned long long u64;
 typedef unsigned int u32;

@@ -43,6 +43,8 @@ class Field:
     Nx: int
     pitch: int
     xorg: int
+    signs: torch.Tensor = None     # sign records (Nz, S, NyP, 4) int64 for `signs_level`, or None
+    signs_level: float = 0.5
 
     def dense(self):
         return self.data[:, :, self.xorg:self.xorg + self.Nx]
@@ -145,9 +147,33 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
     Nz, Ny, Nx = nz + 2 * pad, ny + 2 * pad, nx + 2 * pad
     pitch = L.tomo_field_pitch(nx, pad)
     data = torch.empty((Nz, Ny, pitch), dtype=torch.float32, device=vol.device)
-    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _stream()),
+    xorg = L.tomo_field_xorg(pad)
+    # the field kernel leaves the sign records (marching-cubes pass 1 input) behind as a by-product
+    fused = bool(manifold) and bool(L.tomo_field_signs_fused(nx))
+    signs = None
+    sbuf = None
+    if fused:
+        S, NyP = L.tomo_mc_segments_per_row(Nx, xorg), L.tomo_sign_rows(Ny)
+        sbuf = torch.zeros(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
+        signs = sbuf[: Nz * S * NyP * 4].view(Nz, S, NyP, 4)
+    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _stream()),
                "tomo_field_fill")
-    return Field(data, Nz, Ny, Nx, pitch, L.tomo_field_xorg(pad))
+    if fused:
+        _lib.check(L.tomo_field_signs_finish(_p(data), nz, ny, nx, pad, _p(sbuf), _stream()), "tomo_field_signs_finish")
+    return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5)
+
+
+def field_signs(f: Field, level: float, z_begin: int = 0, z_end: int = None):
+    """Sign records of a float field for slices [z_begin, z_end) (all by default), written into f.signs."""
+    L = _lib.lib()
+    z_end = f.Nz if z_end is None else z_end
+    if f.signs is None:
+        f.signs = torch.empty((f.Nz, L.tomo_mc_segments_per_row(f.Nx, f.xorg), L.tomo_sign_rows(f.Ny), 4),
+                              dtype=torch.int64, device=f.data.device)
+    _lib.check(L.tomo_field_signs(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), z_begin, z_end,
+                                  _p(f.signs), _stream()), "tomo_field_signs")
+    f.signs_level = float(level)
+    return f.signs
 
 
 def field_from_dense(dense: torch.Tensor) -> Field:
@@ -176,8 +202,10 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
     nseg = f.Nz * f.Ny * spr
     # pass 1: active voxels per segment, scan, list of active segments
+    if f.signs is None or f.signs_level != lvl:
+        field_signs(f, lvl)
     seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # zeroed by the call; 32-byte record per segment
-    _lib.check(L.tomo_mc_classify(_p(f.data), *geo, _p(seg_act), st), "tomo_mc_classify")
+    _lib.check(L.tomo_mc_classify(_p(f.signs), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), st), "tomo_mc_classify")
     seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     active_segs = torch.empty(nseg, dtype=torch.int32, device=dev)
     totals = torch.zeros(8, dtype=torch.int64, device=dev)

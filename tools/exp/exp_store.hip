@@ -6,7 +6,7 @@ extern __shared__ u32 s_bits[];
 // mode bit0: stage loads, bit1: second barrier + fake wconst, bit2: persistent over ychunks
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ ext32, float* __restrict__ field, int Ny, int64_t pitch,
-                                               int EY, int EWX32, int mode, int coff)
+                                               int EY, int EWX32, int mode, int coff, unsigned long long* sig)
 {
     const int tid = threadIdx.x;
     const int Z = blockIdx.z, Y0 = blockIdx.y * ROWS;
@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ ext32, fl
     float kf = acc ? 1.0f : 0.0f;
     float* o = field + ((int64_t)Z * Ny + Y0) * pitch + 4 * tid + coff;
     float4 k4 = make_float4(kf, kf, kf, kf);
+    if (mode & 8) {
+        int lane = tid & 63, wave = tid >> 6;
+        for (int Y = Y0; Y < Y1; Y++, o += pitch) {
+            *(float4*)o = k4;
+            if (lane < 4) sig[(((int64_t)Z * Ny + Y) * 5 + wave) * 4 + lane] = (unsigned long long)lane + acc;
+        }
+    } else
     for (int Y = Y0; Y < Y1; Y++, o += pitch) *(float4*)o = k4;
     if (mode & 4) {   // pad columns: lanes < rows of wave 0 / wave 3 store one float each
         int lane = tid & 63, wave = tid >> 6;
@@ -44,14 +51,14 @@ __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ ext32, fl
         }
     }
 }
-extern "C" int exp_store(const void* ext, float* field, int Nz, int Ny, int64_t pitch, int EY, int EWX32, int mode, int rows, int coff, int lds, void* stream)
+extern "C" int exp_store(const void* ext, float* field, int Nz, int Ny, int64_t pitch, int EY, int EWX32, int mode, int rows, int coff, int lds, void* sig, void* stream)
 {
     if (rows == 32) {
         dim3 grid(1, (Ny + 31) / 32, Nz);
-        hipLaunchKernelGGL(k_store<32>, grid, dim3(256), lds, (hipStream_t)stream, (const u32*)ext, field, Ny, pitch, EY, EWX32, mode, coff);
+        hipLaunchKernelGGL(k_store<32>, grid, dim3(256), lds, (hipStream_t)stream, (const u32*)ext, field, Ny, pitch, EY, EWX32, mode, coff, (unsigned long long*)sig);
     } else {
         dim3 grid(1, (Ny + 63) / 64, Nz);
-        hipLaunchKernelGGL(k_store<64>, grid, dim3(256), 5 * 68 * 34 * 4, (hipStream_t)stream, (const u32*)ext, field, Ny, pitch, EY, EWX32, mode, coff);
+        hipLaunchKernelGGL(k_store<64>, grid, dim3(256), 5 * 68 * 34 * 4, (hipStream_t)stream, (const u32*)ext, field, Ny, pitch, EY, EWX32, mode, coff, (unsigned long long*)sig);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

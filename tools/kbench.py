@@ -48,24 +48,25 @@ def main():
         pitch = L.tomo_field_pitch(nx, pad)
         data = torch.empty((nz + 2, ny + 2, pitch), dtype=torch.float32, device=dev)
         t_zero = timeit(lambda: data.zero_())
-        t_field = timeit(lambda: L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), nz, ny, nx, pad, 1, st))
-        f = pipeline.Field(data, nz + 2, ny + 2, nx + 2, pitch, L.tomo_field_xorg(pad))
+        signs = torch.zeros(L.tomo_sign_buffer_words(nz + 2, ny + 2, nx + 2, L.tomo_field_xorg(pad)), dtype=torch.int64, device=dev)
+        t_field = timeit(lambda: L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), nz, ny, nx, pad, 1, signs.data_ptr(), st))
+        t_fin = timeit(lambda: L.tomo_field_signs_finish(data.data_ptr(), nz, ny, nx, pad, signs.data_ptr(), st))
+        f = pipeline.Field(data, nz + 2, ny + 2, nx + 2, pitch, L.tomo_field_xorg(pad), signs[: (nz + 2) * L.tomo_mc_segments_per_row(nx + 2, L.tomo_field_xorg(pad)) * L.tomo_sign_rows(ny + 2) * 4].view(nz + 2, -1, L.tomo_sign_rows(ny + 2), 4), 0.5)
         spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
         nseg = f.Nz * f.Ny * spr
-        seg_na = torch.empty(nseg, dtype=torch.int32, device=dev)
         seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)
-        t_cls = timeit(lambda: L.tomo_mc_classify(data.data_ptr(), f.Nz, f.Ny, f.Nx, pitch, f.xorg, 0.5, seg_act.data_ptr(), st))
+        t_cls = timeit(lambda: L.tomo_mc_classify(signs.data_ptr(), f.Nz, f.Ny, f.Nx, f.xorg, seg_act.data_ptr(), st))
         t_morph = timeit(lambda: pipeline.smooth(vol, 3, True))
         t_close = timeit(lambda: pipeline.close_ends(vol))
         if name != "noise50" or n <= 256:
             t_mc = timeit(lambda: pipeline.marching_cubes(f, 0.5), n=3, warm=1)
         else:
             t_mc = float("nan")
-        print("%-10s n=%d memset %.3f ms (%.0f GB/s) pack %.3f ms (%.0f GB/s) | ext %.3f | field %.3f ms (%.0f GB/s alg) | classify %.3f ms (%.0f GB/s) | "
+        print("%-10s n=%d memset %.3f ms (%.0f GB/s) pack %.3f ms (%.0f GB/s) | ext %.3f | field %.3f ms (%.0f GB/s alg) + signs_finish %.3f | classify %.3f ms (%.0f GB/s) | "
               "smooth %.3f | close %.3f | mc_total %.3f" % (
-                  name, n, t_zero, data.numel() * 4 / t_zero / 1e6, t_pack, n ** 3 / t_pack / 1e6, t_ext, t_field, 5 * Np / t_field / 1e6, t_cls,
+                  name, n, t_zero, data.numel() * 4 / t_zero / 1e6, t_pack, n ** 3 / t_pack / 1e6, t_ext, t_field, 5 * Np / t_field / 1e6, t_fin, t_cls,
                   4 * Np / t_cls / 1e6, t_morph, t_close, t_mc), flush=True)
-        del vol, ext, data, f, seg_na, seg_act
+        del vol, ext, data, f, seg_act, signs
         torch.cuda.empty_cache()
 
 
