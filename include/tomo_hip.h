@@ -74,6 +74,9 @@ int tomo_close_ends_gp(const uint64_t *bits, int nz, int ny, int nx, uint64_t *w
 /* One 6-neighbour pass (skimage binary_erosion/binary_dilation, voxel_processor.py:88,91):
  * op 0 = erosion with border_value 1, op 1 = dilation with border value 0.  in != out. */
 int tomo_morph_pass(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, int op, void *stream);
+/* nops (2, 4, 6 or 8) such passes fused into one kernel: bit j of `ops` is the op of pass j (0 erosion, 1 dilation).
+ * smooth_voxel_data(iterations=3, create_manifold=True) is E D | D E | D E | D E = ops 0b01010110. */
+int tomo_morph_fused(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, uint32_t ops, int nops, void *stream);
 
 /* ---------------------------------------------------------------- scalar field ("SDF") */
 /* bits -> extended bits (reflect of the padded array + zero pad ring), see tomo_ext_*. */

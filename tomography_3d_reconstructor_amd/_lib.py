@@ -40,6 +40,7 @@ SIGNATURES = {
     "tomo_close_ends_scan": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_close_ends_gp": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
     "tomo_morph_pass": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "tomo_morph_fused": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, ctypes.c_uint32, _c_i, _c_p]),
     "tomo_extend_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_field_fill": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_sign_rows": (_c_i64, [_c_i]),

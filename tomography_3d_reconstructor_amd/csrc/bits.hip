@@ -442,6 +442,128 @@ TOMO_API int tomo_morph_pass(const uint64_t *in, uint64_t *out, int nz, int ny, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused smoothing: all H erosion/dilation passes of smooth_voxel_data (voxel_processor.py:79-97) in ONE kernel.
+// A block owns a tile of rows x words (plus an H-row / 1-word halo that it recomputes) and marches along z as a
+// software pipeline: stage j turns level j-1 into level j,
+//     L_j[s] = inplane_j(L_{j-1}[s])  o  L_{j-1}[s-1]  o  L_{j-1}[s+1]          (o = AND for erosion, OR for dilation)
+// where the in-plane part (y+-1 rows, x+-1 bits) needs the neighbours' words: one LDS exchange per stage and
+// slice, two alternating tiles, one barrier per stage.  Per level a thread keeps three words in registers.
+// HBM traffic: ~1.6 x 1 read + 1 write of the bit volume instead of H reads + H writes.
+#define FM_TW 16      // words of a row per tile (a 1024-voxel row is one tile)
+
+__device__ static inline u64 fm_inplane(int op, u64 c, u64 yl, u64 yh, u64 pl, u64 ph, u64 valid)
+{
+    if (op == 0) c |= ~valid;                // bits beyond nx count as outside (=1) for erosion
+    u64 xl = (c << 1) | (pl >> 63), xh = (c >> 1) | (ph << 63);
+    return op == 0 ? (c & yl & yh & xl & xh) : (c | yl | yh | xl | xh);
+}
+
+template <int H, bool ROW16>
+__global__ __launch_bounds__(1024) void morph_fused_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int nz, int ny,
+                                                           int nx, int wx, u32 ops, int rows_own, int zchunk)
+{
+    extern __shared__ u64 fm_tile[];                     // 2 x (TYH x TWH) words
+    const int TWH = blockDim.x, TYH = blockDim.y;        // tile incl. halo
+    const int tw = threadIdx.x, ty = threadIdx.y;
+    const int xh = (wx > FM_TW) ? 1 : 0;                 // x halo only when the row is wider than one tile
+    const int w0 = (int)blockIdx.x * (TWH - 2 * xh);     // first owned word
+    const int w = w0 - xh + tw;
+    const int y0 = (int)blockIdx.y * rows_own;
+    const int y = y0 - H + ty;
+    const int za = (int)blockIdx.z * zchunk, zb = za + zchunk < nz ? za + zchunk : nz;
+    const bool inv = (w >= 0 && w < wx && y >= 0 && y < ny);             // this thread's column exists
+    const bool own = inv && tw >= xh && tw < TWH - xh && ty >= H && ty < TYH - H && y < y0 + rows_own;
+    const u64 tailmask = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
+    const u64 valid = (w == wx - 1) ? tailmask : ~0ull;
+    const int64_t sw = (int64_t)ny * wx;
+    const int64_t col = inv ? (int64_t)y * wx + w : 0;
+    const int tidx = ty * TWH + tw;
+    u64 P[H], L1[H], L2[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) { P[j] = 0; L1[j] = 0; L2[j] = 0; }
+    for (int t = za - H; t < zb + H; t++) {
+        u64 X = (inv && t >= 0 && t < nz) ? in[(int64_t)t * sw + col] : 0ull;   // level 0, slice t
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            // stage j+1 consumes X = L_j[t - j] and produces L_{j+1}[t - j - 1]
+            const int op = (ops >> j) & 1;
+            const u64 B = op == 0 ? ~0ull : 0ull;
+            const int sX = t - j;
+            const u64 Xe = (sX >= 0 && sX < nz) ? X : B;
+            u64 o = op == 0 ? (P[j] & L2[j] & Xe) : (P[j] | L2[j] | Xe);
+            o &= valid;
+            // in-plane part of slice sX for the next iteration: exchange X with the neighbours
+            u64 *tile = fm_tile + (j & 1) * (TYH * TWH);
+            tile[tidx] = X;
+            __syncthreads();
+            u64 yl = (ty > 0) ? tile[tidx - TWH] : B;
+            u64 yh = (ty < TYH - 1) ? tile[tidx + TWH] : B;
+            u64 pl, ph;
+            if (ROW16) {   // a tile row is exactly one 16-lane DPP row: x neighbours without LDS
+                int lo = (int)(u32)X, hi = (int)(u32)(X >> 32);
+                u32 pll = (u32)__builtin_amdgcn_update_dpp(0, lo, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                u32 plh = (u32)__builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false);
+                u32 phl = (u32)__builtin_amdgcn_update_dpp(0, lo, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+                u32 phh = (u32)__builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, false);
+                pl = ((u64)plh << 32) | pll;
+                ph = ((u64)phh << 32) | phl;
+            } else {
+                pl = (tw > 0) ? tile[tidx - 1] : B;
+                ph = (tw < TWH - 1) ? tile[tidx + 1] : B;
+            }
+            if (y <= 0) yl = B;
+            if (y >= ny - 1) yh = B;
+            if (w <= 0) pl = B;
+            if (w >= wx - 1) ph = B;
+            L2[j] = L1[j];
+            L1[j] = Xe;
+            P[j] = fm_inplane(op, X, yl, yh, pl, ph, valid);
+            X = o;
+        }
+        const int so = t - H;                               // slice of the final level that just completed
+        if (own && so >= za && so < zb) out[(int64_t)so * sw + col] = X;
+    }
+}
+
+TOMO_API int tomo_morph_fused(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, uint32_t ops, int nops,
+                              void *stream)
+{
+    if (!in || !out || in == out || nz <= 0 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    if (nops != 2 && nops != 4 && nops != 6 && nops != 8) return TOMO_E_ARG;
+    int wx = (int)tomo_words_per_row(nx);
+    int xh = wx > FM_TW ? 1 : 0;
+    int TWH = (wx > FM_TW ? FM_TW : wx) + 2 * xh;
+    int TYH = 1024 / TWH;
+    if (TYH > 64) TYH = 64;
+    int rows_own = TYH - 2 * nops;
+    if (rows_own < 4) return TOMO_E_SIZE;
+    if (rows_own > ny) { rows_own = ny; TYH = rows_own + 2 * nops; }
+    int zchunk = nz;
+    // enough blocks to fill the chip: split z
+    int64_t tiles = ceil_div64(wx, TWH - 2 * xh) * ceil_div64(ny, rows_own);
+    while (zchunk > 32 && tiles * ceil_div64(nz, zchunk) < 512) zchunk = (zchunk + 1) / 2;
+    dim3 grid((unsigned)ceil_div64(wx, TWH - 2 * xh), (unsigned)ceil_div64(ny, rows_own), (unsigned)ceil_div64(nz, zchunk));
+    dim3 block((unsigned)TWH, (unsigned)TYH);
+    size_t lds = (size_t)2 * TYH * TWH * sizeof(u64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nops) {
+    case 2: if (TWH == 16) hipLaunchKernelGGL((morph_fused_kernel<2, true>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        else hipLaunchKernelGGL((morph_fused_kernel<2, false>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        break;
+    case 4: if (TWH == 16) hipLaunchKernelGGL((morph_fused_kernel<4, true>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        else hipLaunchKernelGGL((morph_fused_kernel<4, false>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        break;
+    case 6: if (TWH == 16) hipLaunchKernelGGL((morph_fused_kernel<6, true>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        else hipLaunchKernelGGL((morph_fused_kernel<6, false>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        break;
+    default: if (TWH == 16) hipLaunchKernelGGL((morph_fused_kernel<8, true>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        else hipLaunchKernelGGL((morph_fused_kernel<8, false>), grid, block, lds, s, (const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, rows_own, zchunk);
+        break;
+    }
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------
 // extended bit volume: ext[ez][ey][e]  <->  padded voxel (Z,Y,X) = (ez-2, ey-2, e-(4-pad)) with the
 // 'reflect' rule of scipy applied on the PADDED array and zeros in the pad ring.  Data column x sits at
 // ext bit x+4 (nibble aligned), so interior words are a 4-bit funnel shift of the source words.

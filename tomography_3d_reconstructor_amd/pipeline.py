@@ -113,25 +113,21 @@ def smooth(vol: BitVolume, iterations: int = 3, create_manifold: bool = True) ->
     nz, ny, nx = vol.shape
     L = _lib.lib()
     a = vol.bits
+    ops = ([0, 1] if create_manifold else []) + [1, 0] * int(iterations)      # 0 = erosion (border 1), 1 = dilation
+    if not ops:
+        return BitVolume(a.clone(), vol.shape)
     bufs = [torch.empty_like(a), torch.empty_like(a)]
     k = 0
-
-    def run(src, op):
-        nonlocal k
+    cur = a
+    i = 0
+    while i < len(ops):
+        n = min(8, len(ops) - i)                   # up to 8 passes per fused launch (n is even: passes come in pairs)
+        mask = sum(op << j for j, op in enumerate(ops[i:i + n]))
         dst = bufs[k]
         k ^= 1
-        _lib.check(L.tomo_morph_pass(_p(src), _p(dst), nz, ny, nx, op, _stream()), "tomo_morph_pass")
-        return dst
-
-    cur = a
-    if create_manifold:
-        cur = run(cur, 0)
-        cur = run(cur, 1)
-    for _ in range(int(iterations)):
-        cur = run(cur, 1)
-        cur = run(cur, 0)
-    if cur is a:
-        cur = a.clone()
+        _lib.check(L.tomo_morph_fused(_p(cur), _p(dst), nz, ny, nx, mask, n, _stream()), "tomo_morph_fused")
+        cur = dst
+        i += n
     return BitVolume(cur, vol.shape)
 
 
