@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--size", type=int, nargs=3, default=None, metavar=("NZ", "NY", "NX"),
                     help="per-rank volume (default 1024 1024 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the cube the CPU oracle is timed on")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the cube the CPU oracle is timed on")
     return ap.parse_args()
 
 
