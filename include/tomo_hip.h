@@ -85,21 +85,17 @@ int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx
  * gaussian_filter(sigma=0.5) (three 5-tap float64 correlate1d passes, axis 0,1,2, mode reflect),
  * cast to float32.  gaussian = 0 writes the raw 0/1 field (manifold=False). */
 int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
-                    unsigned long long *signs, void *stream);
+                    unsigned long long *signs, void *stream);   /* `field` must be 128-byte aligned */
 /* Sign records (input of marching-cubes pass 1): uint64 [Nz][S][NyP][4], S = tomo_mc_segments_per_row(Nx, xorg),
  * NyP = tomo_sign_rows(Ny) (Ny rounded up to 16 so that 16-row groups of records are 512-byte aligned);
  * bit L of word k of record (Z, s, Y) = [field(Z, Y, column 256 s - 224 + 4 L + k) > iso].  tomo_field_fill writes
- * them as a by-product (iso 0.5) when `signs` is not NULL, gaussian = 1 and tomo_field_signs_fused(nx) is 1 -- the
- * caller must have ZEROED the buffer (records of all-zero regions are not written);
+ * them as a by-product (iso 0.5), for every row Y < Ny of every segment, when `signs` is not NULL and gaussian = 1
+ * (no zeroing needed; bits of columns outside the padded row are unspecified and ignored by tomo_mc_classify);
  * tomo_field_signs derives them from any float field for slices [z_begin, z_end). */
 int64_t tomo_sign_rows(int Ny);
-int tomo_field_signs_fused(int nx);
-/* Size (uint64 words) of the buffer passed as `signs` to tomo_field_fill / tomo_field_signs_finish: the records
- * followed by per-chunk flags.  The field kernel writes final records for its constant waves and leaves the sign
- * bits of the other waves lane-major in the record area; tomo_field_signs_finish (to be called right after
- * tomo_field_fill) converts those chunks in place (~1 KB each). */
+int tomo_field_signs_fused(int nx);                      /* 1: tomo_field_fill writes the records itself (always, ABI 2) */
+/* Size (uint64 words) of the buffer passed as `signs` to tomo_field_fill. */
 int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg);
-int tomo_field_signs_finish(const float *field, int nz, int ny, int nx, int pad, unsigned long long *signs, void *stream);
 int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso, int z_begin,
                      int z_end, unsigned long long *signs, void *stream);
 

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtomo_hip.so")
+SO_PATH = os.environ.get("TOMO_LIB") or os.path.join(_HERE, "libtomo_hip.so")   # TOMO_LIB: tuning builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 _c_i = ctypes.c_int
@@ -46,7 +46,6 @@ SIGNATURES = {
     "tomo_sign_rows": (_c_i64, [_c_i]),
     "tomo_field_signs_fused": (_c_i, [_c_i]),
     "tomo_sign_buffer_words": (_c_i64, [_c_i, _c_i, _c_i, _c_i]),
-    "tomo_field_signs_finish": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_field_signs": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_i, _c_i, _c_p, _c_p]),
     "tomo_mc_classify": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_mc_scan_segments": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

@@ -8,40 +8,49 @@
 //     t = x[0]*w0;  t += (x[-2] + x[+2])*w2;  t += (x[-1] + x[+1])*w1;
 // (symmetric branch of NI_Correlate1D), no FMA contraction (-ffp-contract=off), then (float)t.
 //
-// Kernel structure (memory-bound: 1 bit in, 4 B out per padded voxel):
-//   * pass 1 (z): its input is binary, so the result is one of 18 doubles -> an 18-entry LDS LUT
-//     indexed by (centre bit, sum of the +-2 bits, sum of the +-1 bits), four voxels per lookup word;
-//   * pass 2 (y): each lane owns 4 consecutive x columns and marches down y keeping a 5-row window
-//     of pass-1 values in registers (each pass-1 value is looked up once, used 5 times);
-//   * pass 3 (x): needs pass-2 values of the two columns left and right: wave-level DPP shifts, and
-//     one LDS slot per wave edge (double buffered, one barrier per row);
-//   * stores: one aligned float4 per lane per row (1 KiB contiguous per wave);
-//   * wave-uniform fast path: if the 5x5 neighbourhood of a wave's 256 columns is all-0 / all-1 the
-//     result is a constant (computed with the same operation sequence) and no float64 work is done.
-// All border handling (zero pad ring, scipy 'reflect') is already materialised in the extended bit
-// volume (bits.hip: extend_kernel), so the hot loop has no boundary branches except the row ends.
+// Kernel structure (memory-bound: 1 bit in, 4 B out per padded voxel) -- "tile sparse":
+//   * the field row is cut into TILES of 32 float columns (one 128-byte line) x 16 rows; float column c
+//     of a row holds the value of extended bit c - 28 (tomo_extend_bits materialises every border rule, so
+//     there is not a single boundary branch here: pad columns, reflected columns and the unused columns of
+//     the pitch are ordinary outputs);
+//   * a block owns 4 consecutive slices x 16 rows x (up to 64) tiles.  It stages its 8 x 20 input rows of
+//     bits in LDS once (each bit is fetched 2x instead of 5x), reduces them to per-(slice, word) OR / AND,
+//     and classifies every tile by its 5 x 20 x 36-bit neighbourhood: all zero -> the field is 0, all one ->
+//     the field is the interior constant (computed with the same operation sequence), else MIXED;
+//   * constant tiles (94 % of an ellipsoid volume, every tile away from the surface of any volume) are pure
+//     aligned float4 store loops: 1 KiB per wave instruction, whole 128-byte lines only;
+//   * the block's mixed tiles are pooled and computed six at a time per wave, ten lanes per tile (eight
+//     output lanes of four columns + one halo lane on each side): pass 1 (z) has binary input, so it is an
+//     18-entry LDS LUT indexed by a 4-voxel SWAR code word; pass 2 (y) marches down the rows with a 5-row
+//     window in registers; pass 3 (x) takes the neighbours' pass-2 values by DPP wave shifts.  No barrier
+//     and no LDS exchange inside the row loop, full lanes for the float64 work;
+//   * the marching-cubes sign records ([field > 0.5], one bit per voxel) are a by-product: bytes of mixed
+//     tiles through LDS, bytes of constant tiles from the tile class, one 512-byte store per wave.
 #include "tomo_common.h"
 
 #define FW0 0x1.92b965ef5aaefp-1    // exp(-2 x^2)/sum for x = 0, +-1, +-2 as produced by the pinned
 #define FW1 0x1.b405b9842b206p-4    // oracle environment (SciPy 1.7.1 / NumPy 1.26.4)
 #define FW2 0x1.14aebe6a24088p-12
 
+#define FT_ROWS 16                  // rows of a tile = rows of a block
+#define FT_SROWS (FT_ROWS + 4)      // staged rows
+#ifndef FT_ZG
+#define FT_ZG 4                     // slices of a block
+#endif
+#define FT_SLOTS (FT_ZG + 4)        // staged slices
+#define FT_THREADS 256
+#define FT_MAXT 64                  // tiles of a block along x (wider rows: several blocks)
+#define FT_SBMAX 72                 // max bytes per (slice, row, word k) line of the LDS sign area (>= FT_MAXT + 7)
+#define FT_BATCH 24                 // staging loads in flight per thread
+
 struct FieldParams {
-    int nz, ny, nx, pad;
-    int Nz, Ny, Nx;
-    int EY, EWX32;          // ext rows per slice, ext 32-bit words per row
+    int Nz, Ny, NT;                 // field slices, rows, tiles per row (pitch / 32)
+    int EZ, EY, EWX32;              // extended bit volume: slices, rows, 32-bit words per row
     int64_t pitch;
-    int xorg;
-    int nq;                 // data lanes = ceil(nx / 4)
-    int nlanes;             // lanes that compute pass 2 (nq, +1 when nx % 4 != 0)
-    int r;                  // nx % 4
-    int rows_per_block;
-    int W;                  // 32-bit ext words staged per row and block
-    u64 *signs;             // sign records [Z][S][NyP][4] (may be null)
-    int S;                  // marching-cubes segments per row
-    int NyP;                // rows per (Z, segment) block of records: Ny rounded up to 16
-    u32 *sflags;            // per (Z, segment, row chunk): 1 = records final, 0 = lane-major words to convert
-    const float *fieldp;    // (convert kernel) the field, to read the right pad column
+    int nxc, ntr, nzg;              // blocks per row, tile rows, slice groups
+    u64 *signs;                     // sign records [Nz][S][NyP][4] (may be null)
+    int S, NyP;
+    int SB;                         // bytes per (slice, row, word k) line of the LDS sign area: tiles + 7, rounded up to 8
 };
 
 __device__ static inline double tap5(double a, double b, double c, double d, double e)
@@ -52,67 +61,18 @@ __device__ static inline double tap5(double a, double b, double c, double d, dou
     return t;
 }
 
-#define FIELD_MAX_STAGE_ROWS 36   // rows_per_block (<= 32) + 4
-#define FIELD_NW 10               // 32-bit words that can hold a wave's 256 columns + 2 halo bits on each side
-// LDS: [5 slices][rows_per_block + 4 rows][W words] of the extended bit volume (the block's whole input),
-// followed by the per-(slice, word) OR / AND over the rows (2 x 5 x W words).
-extern __shared__ u32 s_bits[];
+// dynamic LDS: u32 s_bits[FT_SLOTS][FT_SROWS][WS] | u32 s_ror[FT_SLOTS][WS] | u32 s_rand[FT_SLOTS][WS] |
+//              (8-byte aligned) u8 s_sign[FT_ZG][FT_ROWS][4][SB]
+extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 
-// The two pad columns X = 0 and X = Nx-1 of the block's rows, from the values collected in LDS.  Isolated
-// 4-byte stores into otherwise untouched 128-byte lines are ~9x as expensive as whole-line stores on this HBM
-// (read-modify-write), so for the common aligned shape (nx % 32 == 0) the whole line around each pad column is
-// written (zeros elsewhere: those columns are outside the field): 8 rows x 128 B per store instruction.
-__device__ static inline void store_pad_columns(float *obase, const FieldParams &p, float (*s_pad)[32], bool w_first,
-                                                bool w_last, int nrows_out, int lane)
-{
-    if ((p.nx & 31) == 0) {
-        const int q = lane & 7;
-        for (int j = 0; j < nrows_out; j += 8) {
-            const int row = j + (lane >> 3);
-            if (row < nrows_out) {
-                float *o = obase + (int64_t)row * p.pitch;
-                if (w_first) *(float4 *)(o + 4 * q) = make_float4(0.f, 0.f, 0.f, q == 7 ? s_pad[0][row] : 0.f);
-                if (w_last) *(float4 *)(o + 32 + p.nx + 4 * q) = make_float4(q == 0 ? s_pad[1][row] : 0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    } else if (lane < nrows_out) {
-        float *o = obase + (int64_t)lane * p.pitch;
-        if (w_first) o[p.xorg] = s_pad[0][lane];
-        if (w_last) o[p.xorg + p.Nx - 1] = s_pad[1][lane];
-    }
-}
-
-// Sign records of the two segments that hold only a pad column: segment 0 (column 31 = X 0 is its lane 63,
-// element 3) and, when the right pad column starts a new segment, segment wave + 2 (its lane 0, element 0).
-__device__ static inline void store_pad_signs(const FieldParams &p, float (*s_pad)[32], bool left, bool right, int Z,
-                                              int wave, int Y0, int nrows_out, int lane)
-{
-    if (lane >= nrows_out) return;
-    if (left) {
-        ulonglong2 *o = (ulonglong2 *)(p.signs + ((((int64_t)Z * p.S + 0) * p.NyP) + Y0 + lane) * 4);
-        o[0] = make_ulonglong2(0ull, 0ull);
-        o[1] = make_ulonglong2(0ull, s_pad[0][lane] > 0.5f ? (1ull << 63) : 0ull);
-    }
-    if (right && wave + 2 < p.S) {
-        ulonglong2 *o = (ulonglong2 *)(p.signs + ((((int64_t)Z * p.S + wave + 2) * p.NyP) + Y0 + lane) * 4);
-        o[0] = make_ulonglong2(s_pad[1][lane] > 0.5f ? 1ull : 0ull, 0ull);
-        o[1] = make_ulonglong2(0ull, 0ull);
-    }
-}
-
-__device__ static inline float p_field_pad(const FieldParams &p, int Z, int Y)
-{
-    return p.fieldp[((int64_t)Z * p.Ny + Y) * p.pitch + p.xorg + p.Nx - 1];
-}
-
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
-                                                           const FieldParams p)
+__global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
+                                                                const FieldParams p)
 {
     __shared__ double s_lut[18];
-    __shared__ double s_halo[2][16][4];
-    __shared__ float s_pad[2][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6, T = blockDim.x;
+    __shared__ unsigned char s_cls[FT_ZG][FT_SBMAX];
+    __shared__ unsigned short s_list[FT_ZG * FT_MAXT];
+    __shared__ int s_nmixed;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = FT_THREADS / 64;
     if (tid < 18) {
         int c = tid / 9, s2 = (tid / 3) % 3, s1 = tid % 3;
         double t = (double)c * FW0;
@@ -120,285 +80,210 @@ __global__ __launch_bounds__(MAXT) void field_gauss_kernel(const u32 *__restrict
         t += (double)s1 * FW1;
         s_lut[tid] = t;
     }
-    const bool multi = gridDim.x > 1;
-    const int tstart = multi ? (int)blockIdx.x * (T - 2) - 1 : 0;
-    const int t = tstart + tid;                     // global lane (4-column group) index
-    const bool valid = t >= 0 && t < p.nlanes;
-    const bool can_out = valid && (!multi || (tid > 0 && tid < T - 1));
-    const int Z = blockIdx.z;
-    const int Y0 = (int)blockIdx.y * p.rows_per_block;
-    const int Y1 = Y0 + p.rows_per_block < p.Ny ? Y0 + p.rows_per_block : p.Ny;
-    const int nrows = Y1 - Y0 + 4;                  // ext rows Y0 .. Y1+3
-    const int e0 = 4 * t + 4;                       // ext bit of this lane's first element
-    const int col0 = 4 * t + 32;                    // its float column in the field row (128-byte aligned per wave)
-    const int sh = e0 & 31;
-    const int wbase = tstart < 0 ? 0 : (4 * tstart + 2) >> 5;   // word of the block's first halo bit
-    const int W = p.W;
-    const int RS = (p.rows_per_block + 4) * W;      // LDS slice stride
-    u32 *const s_or = s_bits + 5 * RS, *const s_and = s_or + 5 * W;
-    // ---- stage the block's input bits: 5 slices x nrows x W words; thread j < 5*W owns (slice k, word w)
-    if (tid < 5 * W) {
-        const int64_t sstride = (int64_t)p.EY * p.EWX32;
-        const int k = tid / W, w = tid - k * W;
-        const bool inb = wbase + w < p.EWX32;
-        const u32 *sp = ext32 + (int64_t)Z * sstride + (int64_t)Y0 * p.EWX32 + wbase + (int64_t)k * sstride + w;
-        u32 *dp = s_bits + k * RS + w;
-        u32 vor = 0u, vand = 0xffffffffu;
+    if (tid == 0) s_nmixed = 0;
+    // ---- which part of the field is this block's
+    const unsigned lin = blockIdx.x;
+    const int bx = (int)(lin % (unsigned)p.nxc);
+    const int tr = (int)((lin / (unsigned)p.nxc) % (unsigned)p.ntr);
+    const int zg = (int)(lin / ((unsigned)p.nxc * (unsigned)p.ntr));
+    // tiles j0 .. j0+nt-1; chunk boundaries fall on marching-cubes segment boundaries ((j + 7) % 8 == 0)
+    const int j0 = bx == 0 ? 0 : FT_MAXT * bx - 7;
+    const int jend = FT_MAXT * bx + FT_MAXT - 7 < p.NT ? FT_MAXT * bx + FT_MAXT - 7 : p.NT;
+    const int nt = jend - j0;
+    const int joff = (j0 + 7) & 7;                  // byte position of tile j0 in its segment's record words
+    const int WS = nt + 1;                          // staged words per row: ext words j0-1 .. j0+nt-1
+    const int Y0 = tr * FT_ROWS, Z0 = zg * FT_ZG, SB = p.SB;
+    u32 *const s_bits = s_dyn;
+    u32 *const s_ror = s_bits + FT_SLOTS * FT_SROWS * WS, *const s_rand = s_ror + FT_SLOTS * WS;
+    unsigned char *const s_sign = (unsigned char *)(s_dyn + (((FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~1));
+
+    // ---- stage the block's input bits: flat copy of [slot][row][word] (slot = ext slice Z0 + slot, row = ext
+    //      row Y0 + row, word = ext word j0 - 1 + widx); everything outside the extended volume reads as zero
+    {
+        const int total = FT_SLOTS * FT_SROWS * WS;
+        int i = tid;
+        int widx = i % WS, rs = i / WS;             // rs = slot * FT_SROWS + row
+        const int dw = FT_THREADS % WS, drs = FT_THREADS / WS;
+        for (int base = 0; base < total; base += FT_BATCH * FT_THREADS) {
+            u32 v[FT_BATCH];
+            int wi = widx, r = rs;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {               // two batches: all loads of a batch are in flight together
-            u32 v[FIELD_MAX_STAGE_ROWS / 2];
-#pragma unroll
-            for (int j = 0; j < FIELD_MAX_STAGE_ROWS / 2; j++) {
-                int yy = h * (FIELD_MAX_STAGE_ROWS / 2) + j;
-                v[j] = (inb && yy < nrows) ? sp[(int64_t)yy * p.EWX32] : 0u;
+            for (int b = 0; b < FT_BATCH; b++) {
+                const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
+                const int ez = Z0 + slot, ey = Y0 + row, gw = j0 - 1 + wi;
+                const bool ok = (base + b * FT_THREADS + tid) < total && ez < p.EZ && ey < p.EY && gw >= 0 && gw < p.EWX32;
+                v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
+                wi += dw; r += drs;
+                if (wi >= WS) { wi -= WS; r++; }
             }
 #pragma unroll
-            for (int j = 0; j < FIELD_MAX_STAGE_ROWS / 2; j++) {
-                int yy = h * (FIELD_MAX_STAGE_ROWS / 2) + j;
-                if (yy < nrows) { dp[yy * W] = v[j]; vor |= v[j]; vand &= v[j]; }
+            for (int b = 0; b < FT_BATCH; b++) {
+                const int idx = base + b * FT_THREADS + tid;
+                if (idx < total) s_bits[idx] = v[b];
             }
+            widx = wi; rs = r;
         }
-        s_or[tid] = vor; s_and[tid] = vand;
     }
     __syncthreads();
-    const int wl = valid ? (e0 >> 5) - wbase : 0;   // this lane's word inside the staged rows
-
-    // element k of this lane is padded column X = 4t + k + pad
-    const int Xfirst = 4 * t + p.pad;
-    const bool full4 = can_out && t < p.nq && (Xfirst + 3 < p.Nx);
-    const bool first_lane = (t == 0);
-    const bool last_r0 = (p.r == 0) && (t == p.nq - 1);
-    const int t0w = tstart + wave * 64;
-    const bool w_first = (0 >= t0w) && (0 < t0w + 64);                                 // wave holds lane t = 0
-    const bool w_last = (p.r == 0) && (p.nq - 1 >= t0w) && (p.nq - 1 < t0w + 64);      // wave holds the last_r0 lane
+    // ---- per (slot, word): OR / AND over the 20 staged rows
+    for (int it = tid; it < FT_SLOTS * WS; it += FT_THREADS) {
+        const int slot = it / WS, w = it - slot * WS;
+        const u32 *bp = s_bits + slot * FT_SROWS * WS + w;
+        u32 o = 0u, a = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < FT_SROWS; r++) { u32 v = bp[r * WS]; o |= v; a &= v; }
+        s_ror[it] = o; s_rand[it] = a;
+    }
+    __syncthreads();
+    // ---- tile classes: 0 all zero, 1 all one, 2 mixed, 3 no such slice.  Tile j reads ext bits [32j-30, 32j+6)
+    //      = bits 2..31 of staged word jl and bits 0..5 of staged word jl+1 (jl = j - j0), 5 slices, 20 rows.
+    for (int it = tid; it < FT_ZG * nt; it += FT_THREADS) {
+        const int z = it / nt, jl = it - z * nt;
+        u32 o = 0u, a = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int q = (z + k) * WS + jl;
+            o |= (s_ror[q] & 0xfffffffcu) | (s_ror[q + 1] & 0x3fu);
+            a &= (s_rand[q] | 0x3u) & (s_rand[q + 1] | ~0x3fu);
+        }
+        int c = o == 0u ? 0 : (a == 0xffffffffu ? 1 : 2);
+        if (Z0 + z >= p.Nz) c = 3;
+        s_cls[z][jl] = (unsigned char)c;
+        if (c == 2) s_list[atomicAdd(&s_nmixed, 1)] = (unsigned short)((z << 8) | jl);
+    }
+    __syncthreads();
 
     // constants of the all-ones interior, produced by the same operation sequence
     const double p1one = s_lut[17];
     const double c2 = tap5(p1one, p1one, p1one, p1one, p1one);
     const double c3 = tap5(c2, c2, c2, c2, c2);
     const float c3f = (float)c3;
+    const int nrows = Y0 + FT_ROWS <= p.Ny ? FT_ROWS : p.Ny - Y0;
 
-    // ---- is the wave's whole neighbourhood (its 256 columns + 2 on each side, all staged rows, 5 slices) constant?
-    int wconst;     // 0 general, 1 all zero, 2 all one
+    // ---- constant tiles: whole-line float4 stores.  The block's part of a slice (16 rows x nt tiles) is swept as a
+    //      flat, row-major list of 128-byte lines, 8 lines (1 KiB) per wave instruction, the four waves interleaved:
+    //      the block writes each slice as one sequential stream (for rows of <= 57 tiles the region is contiguous).
     {
-        const int ebeg = 4 * t0w + 2 > 0 ? 4 * t0w + 2 : 0, eend = 4 * (t0w + 64) + 6;    // ext bits [ebeg, eend)
-        const int wf = (ebeg >> 5) - wbase, nw = ((eend - 1) >> 5) - wbase - wf + 1;      // nw <= FIELD_NW
-        u32 accor = 0u, accand = 0xffffffffu;
-        if (lane < 5 * FIELD_NW) {
-            const int k = lane / FIELD_NW, j = lane - k * FIELD_NW;
-            if (j < nw && wf + j < W) {
-                const int b0 = (wf + j + wbase) << 5;              // first ext bit of this word
-                u32 m = 0xffffffffu;
-                if (b0 < ebeg) m &= 0xffffffffu << (ebeg - b0);
-                if (b0 + 32 > eend) m &= 0xffffffffu >> (b0 + 32 - eend);
-                accor = s_or[k * W + wf + j] & m;
-                accand = s_and[k * W + wf + j] | ~m;
-            }
-        }
-        const bool allz = __all(accor == 0u), allo = __all(accand == 0xffffffffu);
-        wconst = allz ? 1 : (allo ? 2 : 0);
-    }
-    float *const obase = field + ((int64_t)Z * p.Ny + Y0) * p.pitch;
-    // sign records (marching-cubes pass 1 input): wave w of a single-block row is exactly MC segment w + 1
-    const bool do_signs = p.signs != nullptr && !multi;
-    u64 *const srec = do_signs ? p.signs + ((((int64_t)Z * p.S + (wave + 1)) * p.NyP) + Y0) * 4 : nullptr;
-    const int padlane = p.nq - t0w;                 // lane whose element 0 is the right pad column (when nx % 4 == 0)
-    if (do_signs && lane == 0) p.sflags[((int64_t)Z * p.S + (wave + 1)) * gridDim.y + blockIdx.y] = wconst ? 1u : 0u;
-    if (wconst) {   // publish the (constant) pass-2 halo values for both row parities, once
-        const double k2 = wconst == 1 ? 0.0 : c2;
-        if (lane < 8) s_halo[lane >> 2][wave][lane & 3] = k2;
-    }
-    __syncthreads();
-    if (wconst) {
-        // constant field over the wave's columns for every row of the block: a pure store loop, then the wave
-        // ends (terminated waves no longer take part in the block's barriers)
-        const float kf = wconst == 1 ? 0.0f : c3f;
-        const float4 k4 = make_float4(kf, kf, kf, kf);
-        float *o = obase + col0;
-        if (full4) {
-            for (int Y = Y0; Y < Y1; Y++, o += p.pitch) *(float4 *)o = k4;
-        } else if (can_out) {
-            for (int Y = Y0; Y < Y1; Y++, o += p.pitch) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (Xfirst + k < p.Nx) o[k] = kf;
-            }
-        }
-        if (p.pad && (w_first || w_last)) {                        // pad columns: their bits are zero => wconst == 1
-            if (lane < 32) { if (w_first) s_pad[0][lane] = 0.0f; if (w_last) s_pad[1][lane] = 0.0f; }
-            store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
-        }
-        if (do_signs) {
-            if (wconst == 2)                               // all-zero waves: the caller zeroed the buffer
-                for (int j = 0; j < Y1 - Y0; j += 16) {    // 16 rows x 32 B = one 512-byte store
-                    int nr = Y1 - Y0 - j < 16 ? Y1 - Y0 - j : 16;
-                    if (lane < 4 * nr) srec[(int64_t)j * 4 + lane] = ~0ull;
+        const int nlines = nrows * nt;
+        const float inv_nt = 1.0f / (float)nt;
+        for (int z = 0; z < FT_ZG && Z0 + z < p.Nz; z++) {
+            float *zbase = field + ((int64_t)(Z0 + z) * p.Ny + Y0) * p.pitch + 32 * j0 + 4 * (lane & 7);
+            for (int line = 8 * wave + (lane >> 3); line < nlines; line += 8 * nwaves) {
+                const int row = (int)(((float)line + 0.5f) * inv_nt);      // exact: line < 1024, nt <= 64
+                const int jl = line - row * nt;
+                const int c = s_cls[z][jl];
+                if (c < 2) {
+                    const float kf = c ? c3f : 0.0f;
+                    *(float4 *)(zbase + (int64_t)row * p.pitch + 32 * jl) = make_float4(kf, kf, kf, kf);
                 }
-            store_pad_signs(p, s_pad, w_first, w_last && padlane == 64, Z, wave, Y0, Y1 - Y0, lane);
+            }
         }
-        return;
     }
 
-    // pass-1 code word of staged row yy: 4 bytes, byte k = 9*c + 3*s2 + s1 of column k
+    // ---- mixed tiles: six per wave pass, ten lanes per tile (lanes 1..8 own the tile's 32 columns, lanes 0 and 9
+    //      compute the pass-2 values of the halo columns)
+    const int nmixed = s_nmixed;
+    const int SS = FT_SROWS * WS;                   // LDS slot stride
+    for (int ch = wave; ch * 6 < nmixed; ch += nwaves) {
+        const int g = lane / 10, l = lane - 10 * g;
+        const int ti = ch * 6 + g;
+        const bool act = lane < 60 && ti < nmixed;
+        const u32 ent = act ? (u32)s_list[ti] : 0u;
+        const int z = (int)(ent >> 8), jl = (int)(ent & 0xffu);
+        // this lane's four columns start at float column 32 (j0+jl) - 4 + 4 l = ext bit 32 (j0+jl-1) + 4 l
+        const u32 *bp = s_bits + z * SS + jl + (l >= 8 ? 1 : 0);
+        const int sh = (4 * l) & 31;
+        const bool st = act && l >= 1 && l <= 8;
+        float *orow = field + ((int64_t)(Z0 + z) * p.Ny + Y0) * p.pitch + 32 * (j0 + jl) + 4 * (l - 1);
+        unsigned char *sg = s_sign + ((z * FT_ROWS) * 4 + (l - 1)) * SB + jl + joff;   // lanes l = 1..4 write word k = l-1
+        const int bsh = 10 * g + 1;
+
 #define SPREAD(n) ((((n) >> sh) & 0xFu) * 0x00204081u & 0x01010101u)
-#define CODES(yy, dst)                                                                          \
-    {                                                                                           \
-        const u32 *rp = s_bits + (yy) * W + wl;                                                 \
-        u32 n0 = rp[0], n1 = rp[RS], n2 = rp[2 * RS], n3 = rp[3 * RS], n4 = rp[4 * RS];         \
-        dst = valid ? (SPREAD(n2) * 9u + (SPREAD(n0) + SPREAD(n4)) * 3u + (SPREAD(n1) + SPREAD(n3))) : 0u; \
-    }
+        // pass-1 code word of staged row yy: 4 bytes, byte k = 9*c + 3*s2 + s1 of column k
+#define CODES(yy, dst)                                                                                  \
+        {                                                                                               \
+            const u32 *rp = bp + (yy) * WS;                                                             \
+            u32 n0 = rp[0], n1 = rp[SS], n2 = rp[2 * SS], n3 = rp[3 * SS], n4 = rp[4 * SS];             \
+            dst = SPREAD(n2) * 9u + (SPREAD(n0) + SPREAD(n4)) * 3u + (SPREAD(n1) + SPREAD(n3));         \
+        }
 #define LOOKUP(dst, c)                                    \
-    {                                                     \
-        dst[0] = s_lut[(c) & 0xffu];                      \
-        dst[1] = s_lut[((c) >> 8) & 0xffu];               \
-        dst[2] = s_lut[((c) >> 16) & 0xffu];              \
-        dst[3] = s_lut[(c) >> 24];                        \
-    }
-
-    double wa[4], wb[4], wc[4], wd[4], we[4];
-    u32 ca, cb, cc, cd, ce;
-    CODES(0, ca); LOOKUP(wa, ca);
-    CODES(1, cb); LOOKUP(wb, cb);
-    CODES(2, cc); LOOKUP(wc, cc);
-    CODES(3, cd); LOOKUP(wd, cd);
-    int buf = 0;
-
-    // one row: window rows (A,B,C,D,E) = Y-2..Y+2; E enters from staged row (Y - Y0) + 4
-#define STEP(A, B, C, D, E, cA, cB, cC, cD, cE)                                                        \
-    {                                                                                                  \
-        CODES(Y - Y0 + 4, cE);                                                                         \
-        const bool z0 = (cA | cB | cC | cD | cE) == 0u;                                                \
-        const bool o1 = (cA & cB & cC & cD & cE) == 0x11111111u;                                       \
-        const bool wz = __all(z0), wo = __all(o1);                                                     \
-        const bool wu = wz || wo;                                                                      \
-        const double K = wz ? 0.0 : c2;                                                                \
-        double q0, q1, q2, q3;                                                                         \
-        if (wu) { q0 = q1 = q2 = q3 = K; E[0] = E[1] = E[2] = E[3] = wz ? 0.0 : p1one; }               \
-        else {                                                                                         \
-            LOOKUP(E, cE);                                                                             \
-            q0 = tap5(A[0], B[0], C[0], D[0], E[0]);                                                   \
-            q1 = tap5(A[1], B[1], C[1], D[1], E[1]);                                                   \
-            q2 = tap5(A[2], B[2], C[2], D[2], E[2]);                                                   \
-            q3 = tap5(A[3], B[3], C[3], D[3], E[3]);                                                   \
-        }                                                                                              \
-        if (lane == 0) { s_halo[buf][wave][0] = q0; s_halo[buf][wave][1] = q1; }                       \
-        if (lane == 63) { s_halo[buf][wave][2] = q2; s_halo[buf][wave][3] = q3; }                      \
-        __syncthreads();                                                                               \
-        /* pass-2 values of the two columns left / right of this lane's four */                        \
-        double L2 = K, L3 = K, R0 = K, R1 = K;                                                         \
-        if (lane == 0) {                                                                               \
-            if (wave > 0) { L2 = s_halo[buf][wave - 1][2]; L3 = s_halo[buf][wave - 1][3]; }            \
-            else { L2 = 0.0; L3 = 0.0; }                                                               \
-        }                                                                                              \
-        if (lane == 63) {                                                                              \
-            if (wave < nwaves - 1) { R0 = s_halo[buf][wave + 1][0]; R1 = s_halo[buf][wave + 1][1]; }   \
-            else { R0 = 0.0; R1 = 0.0; }                                                               \
-        }                                                                                              \
-        buf ^= 1;                                                                                      \
-        if (first_lane) { L2 = p.pad ? 0.0 : q1; L3 = p.pad ? 0.0 : q0; }                              \
-        if (last_r0) { R0 = p.pad ? 0.0 : q3; R1 = p.pad ? 0.0 : q2; }                                 \
-        float o0, o1f, o2, o3;                                                                         \
-        const bool uni = wu && __all(L2 == K && L3 == K && R0 == K && R1 == K);                        \
-        if (uni) { o0 = o1f = o2 = o3 = wz ? 0.0f : c3f; }                                             \
-        else {                                                                                         \
-            double l2 = dpp_from_prev_f64(q2), l3 = dpp_from_prev_f64(q3);                             \
-            double r0 = dpp_from_next_f64(q0), r1 = dpp_from_next_f64(q1);                             \
-            if (lane != 0) { L2 = l2; L3 = l3; }                                                       \
-            if (lane != 63) { R0 = r0; R1 = r1; }                                                      \
-            if (first_lane) { L2 = p.pad ? 0.0 : q1; L3 = p.pad ? 0.0 : q0; }                          \
-            if (last_r0) { R0 = p.pad ? 0.0 : q3; R1 = p.pad ? 0.0 : q2; }                             \
-            o0 = (float)tap5(L2, L3, q0, q1, q2);                                                      \
-            o1f = (float)tap5(L3, q0, q1, q2, q3);                                                     \
-            o2 = (float)tap5(q0, q1, q2, q3, R0);                                                      \
-            o3 = (float)tap5(q1, q2, q3, R0, R1);                                                      \
-        }                                                                                              \
-        if (do_signs) {   /* 4 sign bits of this lane and row; 8 rows per word, stored lane-major (256 B per wave) */ \
-            u32 n4 = ((u32)(0x3F000000 - __float_as_int(o0)) >> 31) | (((u32)(0x3F000000 - __float_as_int(o1f)) >> 31) << 1) | \
-                     (((u32)(0x3F000000 - __float_as_int(o2)) >> 31) << 2) | (((u32)(0x3F000000 - __float_as_int(o3)) >> 31) << 3); \
-            nibacc |= n4 << (((Y - Y0) & 7) * 4);                                                      \
-            if (((Y - Y0) & 7) == 7 || Y == Y1 - 1) {                                                  \
-                ((u32 *)srec)[(int64_t)((Y - Y0) >> 3) * 64 + lane] = nibacc;                          \
-                nibacc = 0;                                                                            \
-            }                                                                                          \
-        }                                                                                              \
-        if (full4) {                                                                                   \
-            *(float4 *)(orow + col0) = make_float4(o0, o1f, o2, o3);                                     \
-        } else if (can_out) {                                                                          \
-            if (Xfirst + 0 < p.Nx) orow[col0 + 0] = o0;                                                  \
-            if (Xfirst + 1 < p.Nx) orow[col0 + 1] = o1f;                                                 \
-            if (Xfirst + 2 < p.Nx) orow[col0 + 2] = o2;                                                  \
-            if (Xfirst + 3 < p.Nx) orow[col0 + 3] = o3;                                                  \
-        }                                                                                              \
-        if (p.pad && can_out) {   /* pad columns X = 0 / Nx-1 (pass-2 value there is 0): kept in LDS, stored once */ \
-            if (first_lane) { double s = 0.0; s += (q0 + q1) * FW2; s += q0 * FW1; s_pad[0][Y - Y0] = (float)s; } \
-            if (last_r0) { double s = 0.0; s += (q2 + q3) * FW2; s += q3 * FW1; s_pad[1][Y - Y0] = (float)s; }   \
-        }                                                                                              \
-        orow += p.pitch;                                                                               \
-    }
-
-    // sign bits of this lane: 4 per row, 8 rows per register, parked in LDS per 8 rows and turned into records
-    // after the row loop (keeps ballots / SGPR pressure out of the hot loop)
-    u32 nibacc = 0;
-    float *orow = obase;
-    int Y = Y0;
-    while (Y < Y1) {
-        STEP(wa, wb, wc, wd, we, ca, cb, cc, cd, ce); if (++Y >= Y1) break;
-        STEP(wb, wc, wd, we, wa, cb, cc, cd, ce, ca); if (++Y >= Y1) break;
-        STEP(wc, wd, we, wa, wb, cc, cd, ce, ca, cb); if (++Y >= Y1) break;
-        STEP(wd, we, wa, wb, wc, cd, ce, ca, cb, cc); if (++Y >= Y1) break;
-        STEP(we, wa, wb, wc, wd, ce, ca, cb, cc, cd); ++Y;
-    }
-    if (p.pad && (w_first || w_last)) {
-        store_pad_columns(obase, p, s_pad, w_first, w_last, Y1 - Y0, lane);
-        if (do_signs) store_pad_signs(p, s_pad, w_first, w_last && padlane == 64, Z, wave, Y0, Y1 - Y0, lane);
-    }
+        {                                                 \
+            dst[0] = s_lut[(c) & 0xffu];                  \
+            dst[1] = s_lut[((c) >> 8) & 0xffu];           \
+            dst[2] = s_lut[((c) >> 16) & 0xffu];          \
+            dst[3] = s_lut[(c) >> 24];                    \
+        }
+        // one output row r: window rows (A,B,C,D,E) = staged rows r .. r+4
+#define STEP(A, B, C, D, E)                                                                             \
+        {                                                                                               \
+            u32 cE;                                                                                     \
+            CODES(r + 4, cE);                                                                           \
+            LOOKUP(E, cE);                                                                              \
+            const double q0 = tap5(A[0], B[0], C[0], D[0], E[0]);                                       \
+            const double q1 = tap5(A[1], B[1], C[1], D[1], E[1]);                                       \
+            const double q2 = tap5(A[2], B[2], C[2], D[2], E[2]);                                       \
+            const double q3 = tap5(A[3], B[3], C[3], D[3], E[3]);                                       \
+            const double L2 = dpp_from_prev_f64(q2), L3 = dpp_from_prev_f64(q3);                        \
+            const double R0 = dpp_from_next_f64(q0), R1 = dpp_from_next_f64(q1);                        \
+            const float o0 = (float)tap5(L2, L3, q0, q1, q2);                                           \
+            const float o1 = (float)tap5(L3, q0, q1, q2, q3);                                           \
+            const float o2 = (float)tap5(q0, q1, q2, q3, R0);                                           \
+            const float o3 = (float)tap5(q1, q2, q3, R0, R1);                                           \
+            if (st && r < nrows) *(float4 *)orow = make_float4(o0, o1, o2, o3);                         \
+            orow += p.pitch;                                                                            \
+            if (do_signs) {                                                                             \
+                const u64 b0 = __ballot(o0 > 0.5f), b1 = __ballot(o1 > 0.5f);                           \
+                const u64 b2 = __ballot(o2 > 0.5f), b3 = __ballot(o3 > 0.5f);                           \
+                const u64 bk = l == 1 ? b0 : (l == 2 ? b1 : (l == 3 ? b2 : b3));                        \
+                if (act && l >= 1 && l <= 4) sg[r * 4 * SB] = (unsigned char)(bk >> bsh);            \
+            }                                                                                           \
+        }
+        const bool do_signs = p.signs != nullptr;
+        double wa[4], wb[4], wc[4], wd[4], we[4];
+        {
+            u32 c;
+            CODES(0, c); LOOKUP(wa, c);
+            CODES(1, c); LOOKUP(wb, c);
+            CODES(2, c); LOOKUP(wc, c);
+            CODES(3, c); LOOKUP(wd, c);
+        }
+        int r = 0;
+        while (r < FT_ROWS) {
+            STEP(wa, wb, wc, wd, we); if (++r >= FT_ROWS) break;
+            STEP(wb, wc, wd, we, wa); if (++r >= FT_ROWS) break;
+            STEP(wc, wd, we, wa, wb); if (++r >= FT_ROWS) break;
+            STEP(wd, we, wa, wb, wc); if (++r >= FT_ROWS) break;
+            STEP(we, wa, wb, wc, wd); ++r;
+        }
 #undef STEP
 #undef LOOKUP
 #undef CODES
 #undef SPREAD
-}
-
-// The non-constant waves of the field kernel leave their sign bits LANE-MAJOR in the record area (one 32-bit word
-// per lane and 8 rows: bit 4r+k = element k of row r); this turns them into the ballot records the classify pass
-// reads (bit L of word k of row r), in place.  One wave per flagged (Z, segment, chunk of rows): ~1 KB each.
-__global__ __launch_bounds__(256) void field_signs_convert_kernel(FieldParams p, int nchunks, int nwaves, int64_t ntasks)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (Z, wave, chunk), chunk fastest
-    if (task >= ntasks) return;
-    const int chunk = (int)(task % nchunks);
-    const int64_t tz = task / nchunks;
-    const int wave = (int)(tz % nwaves), s = wave + 1;
-    const int Z = (int)(tz / nwaves);
-    if (p.sflags[((int64_t)Z * p.S + s) * nchunks + chunk] != 0u) return;
-    const int Y0 = chunk * p.rows_per_block;
-    const int nr = (Y0 + p.rows_per_block < p.Ny ? p.rows_per_block : p.Ny - Y0);
-    u64 *srec = p.signs + ((((int64_t)Z * p.S + s) * p.NyP) + Y0) * 4;
-    u32 w[4];
+    }
+    if (p.signs == nullptr) return;
+    __syncthreads();
+    // ---- sign records of the block: per (slice, segment) 16 rows x 4 words = one 512-byte store per wave.
+    //      Byte b of a word = tile 8 (segment) - 7 + b: 0x00 / 0xff for a constant tile, the LDS byte for a mixed one.
+    {
+        const int nsegl = (nt + joff + 7) >> 3;
+        const int s0 = (j0 + 7) >> 3;
+        const int r = lane >> 2, k = lane & 3;
+        for (int it = wave; it < FT_ZG * nsegl; it += nwaves) {
+            const int z = it / nsegl, sl = it - z * nsegl;
+            const int Z = Z0 + z, s = s0 + sl;
+            if (Z >= p.Nz || s >= p.S) continue;
+            u64 cm = 0ull, mm = 0ull;
 #pragma unroll
-    for (int g = 0; g < 4; g++) w[g] = (g * 8 < nr) ? ((const u32 *)srec)[g * 64 + lane] : 0u;
-    // right pad column = element 0 of lane `padlane` of the last wave: its value was computed separately
-    const int t0w = wave * 64, padlane = p.nq - t0w;
-    const bool patch = p.pad && p.r == 0 && padlane >= 0 && padlane < 64;
-    u64 rec = 0;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-#pragma unroll
-        for (int rr = 0; rr < 8; rr++) {
-            const int r = g * 8 + rr;
-            u32 n4 = (w[g] >> (rr * 4)) & 15u;
-            if (patch && lane == padlane && r < nr) {
-                float pv = p_field_pad(p, Z, Y0 + r);
-                n4 = (n4 & ~1u) | (pv > 0.5f ? 1u : 0u);
+            for (int b = 0; b < 8; b++) {
+                const int jl = 8 * sl + b - joff;
+                const int c = (jl >= 0 && jl < nt) ? s_cls[z][jl] : 3;
+                if (c == 1) cm |= 0xffull << (8 * b);
+                if (c == 2) mm |= 0xffull << (8 * b);
             }
-            u64 b0 = __ballot(n4 & 1u), b1 = __ballot(n4 & 2u), b2 = __ballot(n4 & 4u), b3 = __ballot(n4 & 8u);
-            const int r16 = r & 15;
-            if ((lane >> 2) == r16) rec = (lane & 3) == 0 ? b0 : ((lane & 3) == 1 ? b1 : ((lane & 3) == 2 ? b2 : b3));
-            if (r < nr && (r16 == 15 || r == nr - 1)) {
-                if (lane < 4 * (r16 + 1)) srec[(int64_t)(r - r16) * 4 + lane] = rec;
-            }
+            const u64 v = cm | (*(const u64 *)(s_sign + ((z * FT_ROWS + r) * 4 + k) * SB + 8 * sl) & mm);
+            if (r < nrows) p.signs[((((int64_t)Z * p.S + s) * p.NyP) + Y0 + r) * 4 + k] = v;
         }
     }
-    if (lane == 0) p.sflags[((int64_t)Z * p.S + s) * nchunks + chunk] = 1u;   // converted: a second call is a no-op
 }
 
 // manifold=False: the field is the raw 0/1 volume (surface_extractor.py:46 without the Gaussian).
@@ -416,88 +301,59 @@ __global__ __launch_bounds__(256) void field_raw_kernel(const u64 *__restrict__ 
     field[((int64_t)Z * Ny + Y) * pitch + xorg + X] = (float)((w >> (e & 63)) & 1ull);
 }
 
-static void fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs)
+static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs)
 {
-    p.nz = nz; p.ny = ny; p.nx = nx; p.pad = pad;
-    p.Nz = nz + 2 * pad; p.Ny = ny + 2 * pad; p.Nx = nx + 2 * pad;
+    p.Nz = nz + 2 * pad; p.Ny = ny + 2 * pad;
+    const int Nx = nx + 2 * pad;
+    p.EZ = (int)tomo_ext_slices(nz, pad);
     p.EY = (int)tomo_ext_rows(ny, pad);
     p.EWX32 = 2 * (int)tomo_ext_words_per_row(nx, pad);
     p.pitch = tomo_field_pitch(nx, pad);
-    p.xorg = tomo_field_xorg(pad);
-    p.nq = (nx + 3) / 4;
-    p.r = nx % 4;
-    p.nlanes = p.nq + (p.r ? 1 : 0);
-    int threads = (p.nlanes + 63) / 64 * 64;
-    if (threads > 1024) threads = 1024;
-    p.rows_per_block = threads <= 256 ? 32 : 16;
-    p.W = (4 * threads + 4 + 31) / 32 + 1;
-    if (p.W > p.EWX32) p.W = p.EWX32;
-    p.S = (int)tomo_mc_segments_per_row(p.Nx, p.xorg);
+    p.NT = (int)(p.pitch / 32);
+    p.nxc = (p.NT + 7 + FT_MAXT - 1) / FT_MAXT;
+    p.ntr = (p.Ny + FT_ROWS - 1) / FT_ROWS;
+    p.nzg = (p.Nz + FT_ZG - 1) / FT_ZG;
+    p.S = (int)tomo_mc_segments_per_row(Nx, tomo_field_xorg(pad));
     p.NyP = (int)tomo_sign_rows(p.Ny);
     p.signs = (u64 *)signs;
-    p.fieldp = nullptr;
-    p.sflags = signs ? (u32 *)((u64 *)signs + (int64_t)p.Nz * p.S * p.NyP * 4) : nullptr;
+    int ntmax = p.NT < FT_MAXT ? p.NT : FT_MAXT;     // tiles of the widest block
+    int WS = ntmax + 1;
+    size_t words = (((size_t)(FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~(size_t)1);
+    p.SB = (ntmax + 7 + 7) & ~7;
+    return words * sizeof(u32) + (signs ? (size_t)FT_ZG * FT_ROWS * 4 * p.SB : 0);
 }
 
 TOMO_API int tomo_field_signs_fused(int nx)
-{   // does tomo_field_fill(gaussian = 1) write the sign records itself for this row width?  (one block per row)
-    int nq = (nx + 3) / 4, nlanes = nq + ((nx % 4) ? 1 : 0);
-    return (nlanes + 63) / 64 * 64 <= 1024 ? 1 : 0;
+{   // does tomo_field_fill(gaussian = 1) write the sign records itself for this row width?  (always, since ABI 2)
+    (void)nx;
+    return 1;
 }
 
 TOMO_API int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg)
-{   // uint64 words: the sign records [Nz][S][NyP][4] followed by the field kernel's per-chunk flags
+{   // uint64 words of the sign records [Nz][S][NyP][4]
     int64_t S = tomo_mc_segments_per_row(Nx, xorg), NyP = tomo_sign_rows(Ny);
-    int64_t chunks = (Ny + 15) / 16;
-    return (int64_t)Nz * S * NyP * 4 + ((int64_t)Nz * S * chunks + 1) / 2 + 8;
-}
-
-// Second step of the fused sign records: convert the lane-major words of the non-constant waves (see the kernel).
-TOMO_API int tomo_field_signs_finish(const float *field, int nz, int ny, int nx, int pad, unsigned long long *signs,
-                                     void *stream)
-{
-    if (!field || !signs || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
-    if (!tomo_field_signs_fused(nx)) return TOMO_E_ARG;
-    FieldParams p;
-    fill_params(p, nz, ny, nx, pad, signs);
-    p.fieldp = field;
-    int nchunks = (int)ceil_div64(p.Ny, p.rows_per_block);
-    int nwaves = (p.nlanes + 63) / 64;
-    int64_t ntasks = (int64_t)p.Nz * nwaves * nchunks;
-    int64_t blocks = ceil_div64(ntasks, 4);
-    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(field_signs_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, nchunks,
-                       nwaves, ntasks);
-    return tomo_status();
+    return (int64_t)Nz * S * NyP * 4 + 8;
 }
 
 TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
                              unsigned long long *signs, void *stream)
 {
     if (!ext || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
+    if (((uintptr_t)field & 127u) != 0) return TOMO_E_ARG;
     FieldParams p;
-    fill_params(p, nz, ny, nx, pad, (gaussian && tomo_field_signs_fused(nx)) ? signs : nullptr);
+    size_t lds = fill_params(p, nz, ny, nx, pad, gaussian ? signs : nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (!gaussian) {
-        int64_t total = (int64_t)p.Nz * p.Ny * p.Nx;
+        const int Nx = nx + 2 * pad;
+        int64_t total = (int64_t)p.Nz * p.Ny * Nx;
         int64_t blocks = ceil_div64(total, 256);
         if (blocks > 0x7fffffff) return TOMO_E_SIZE;
         hipLaunchKernelGGL(field_raw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const u64 *)ext, field, p.Nz, p.Ny,
-                           p.Nx, pad, p.EY, p.EWX32 / 2, p.pitch, p.xorg);
+                           Nx, pad, p.EY, p.EWX32 / 2, p.pitch, tomo_field_xorg(pad));
         return tomo_status();
     }
-    if (p.Nz > 65535) return TOMO_E_SIZE;
-    int threads = (p.nlanes + 63) / 64 * 64;
-    unsigned gx = 1;
-    if (threads > 1024) {
-        threads = 1024;
-        gx = (unsigned)ceil_div64(p.nlanes, threads - 2);
-    }
-    size_t lds = ((size_t)5 * (p.rows_per_block + 4) * p.W + 10 * p.W) * sizeof(u32);
-    dim3 grid(gx, (unsigned)ceil_div64(p.Ny, p.rows_per_block), (unsigned)p.Nz);
-    if (threads <= 256)
-        hipLaunchKernelGGL(field_gauss_kernel<256>, grid, dim3(threads), lds, s, (const u32 *)ext, field, p);
-    else
-        hipLaunchKernelGGL(field_gauss_kernel<1024>, grid, dim3(threads), lds, s, (const u32 *)ext, field, p);
+    int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg;
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(field_tile_kernel, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)ext, field, p);
     return tomo_status();
 }

@@ -150,12 +150,10 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
     sbuf = None
     if fused:
         S, NyP = L.tomo_mc_segments_per_row(Nx, xorg), L.tomo_sign_rows(Ny)
-        sbuf = torch.zeros(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
+        sbuf = torch.empty(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
         signs = sbuf[: Nz * S * NyP * 4].view(Nz, S, NyP, 4)
     _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _stream()),
                "tomo_field_fill")
-    if fused:
-        _lib.check(L.tomo_field_signs_finish(_p(data), nz, ny, nx, pad, _p(sbuf), _stream()), "tomo_field_signs_finish")
     return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5)
 
 

@@ -50,7 +50,7 @@ def main():
         t_zero = timeit(lambda: data.zero_())
         signs = torch.zeros(L.tomo_sign_buffer_words(nz + 2, ny + 2, nx + 2, L.tomo_field_xorg(pad)), dtype=torch.int64, device=dev)
         t_field = timeit(lambda: L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), nz, ny, nx, pad, 1, signs.data_ptr(), st))
-        t_fin = timeit(lambda: L.tomo_field_signs_finish(data.data_ptr(), nz, ny, nx, pad, signs.data_ptr(), st))
+        t_fin = 0.0
         f = pipeline.Field(data, nz + 2, ny + 2, nx + 2, pitch, L.tomo_field_xorg(pad), signs[: (nz + 2) * L.tomo_mc_segments_per_row(nx + 2, L.tomo_field_xorg(pad)) * L.tomo_sign_rows(ny + 2) * 4].view(nz + 2, -1, L.tomo_sign_rows(ny + 2), 4), 0.5)
         spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
         nseg = f.Nz * f.Ny * spr
