@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, nargs=3, default=None, metavar=("NZ", "NY", "NX"),
                     help="per-rank volume (default 1024 1024 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +82,7 @@ class FieldTimer:
 
 def one_pass(mask, depths):
     vol = pipeline.pack(mask)
-    vol = pipeline.close_ends(vol)
+    vol = pipeline.close_ends(vol, inplace=True)       # the packed copy is this pass's own
     vol = pipeline.smooth(vol, 3, True)
     return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
 

@@ -108,15 +108,15 @@ int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, 
  * vertex/voxel key = (row << 22) | (X << 2) | slot, row = Z*Ny + Y; slot 0/1/2 = x/y/z edge owned by the
  * voxel, 3 = cell-centre vertex (voxel keys have slot 0).
  *
- * 1. classify: from the sign records, for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose bit L
- *    says voxel 4L+k of the segment (X = 256 s - 224 + 4L + k - xorg) is active; the call first zeroes the whole
- *    array (seg_act: uint64[4*nseg], seg = (Z*Ny + Y)*S + s) so empty segments read as 0.  No float is read. */
+ * 1. classify: from the sign records, seg_cnt[seg] = number of active voxels of EVERY segment (uint32[nseg],
+ *    seg = (Z*Ny + Y)*S + s) and, for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose bit L says
+ *    voxel 4L+k of the segment (X = 256 s - 224 + 4L + k - xorg) is active (seg_act: uint64[4*nseg]; records of
+ *    empty segments stay unwritten and are never read).  No float is read. */
 int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg, unsigned long long *seg_act,
-                     void *stream);
-/* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of the per-segment active-voxel counts
- * (popcount of the seg_act record), active_segs uint32[nseg] = indices of the non-empty segments in order,
- * totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */
-int tomo_mc_scan_segments(const unsigned long long *seg_act, int64_t nseg, uint32_t *seg_aoff, uint32_t *active_segs,
+                     uint32_t *seg_cnt, void *stream);
+/* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of seg_cnt, active_segs uint32[nseg] = indices
+ * of the non-empty segments in order, totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */
+int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff, uint32_t *active_segs,
                           unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* Exclusive scan of packed counts (low 16 bits -> off_a, high 16 bits -> off_b; both uint32[n + 1], off_b may
  * be NULL), list of the indices of the non-zero entries (nz_ids uint32[n], may be NULL) and

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void field_signs_kernel(const float *__restric
 
 // One LANE per (Z, s, Y): the active-voxel ballots of the segment from the sign records of the four rows
 // (Z,Y) (Z,Y+1) (Z+1,Y) (Z+1,Y+1) (neighbours clamped at the volume border) -- 64-bit logic only.
-// For every non-empty segment the four ballots go, as one aligned 32-byte record, into the zeroed seg_act.
+// Every segment gets its number of active voxels in seg_cnt (what the scan reads: 4 B instead of 32 B per segment);
+// the four ballots of a NON-EMPTY segment go, as one aligned 32-byte record, into seg_act (other records stay unwritten
+// and are never read).
 struct Rec4 { u64 b[4]; };
 
 __device__ static inline Rec4 load_rec(const u64 *__restrict__ signs, int64_t idx)
@@ -86,7 +88,8 @@ __device__ static inline Rec4 load_rec(const u64 *__restrict__ signs, int64_t id
 }
 
 __global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__restrict__ signs, const McGrid g,
-                                                               int64_t ntasks, u64 *__restrict__ seg_act)
+                                                               int64_t ntasks, u64 *__restrict__ seg_act,
+                                                               u32 *__restrict__ seg_cnt)
 {
     const int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (Z, s, Y), Y fastest
     if (task >= ntasks) return;
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__rest
     const int S = g.segs_per_row;
     const int Yn = Y + 1 < g.Ny ? Y + 1 : g.Ny - 1, Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
     const int Xbase = s * SEG - SEG_SHIFT - g.xorg;      // X of (lane 0, k 0)
-    if (Xbase >= g.Nx || Xbase + SEG <= 0) return;       // no voxel of the row in this segment
+    const int64_t segi = ((int64_t)Z * g.Ny + Y) * S + s;
+    if (Xbase >= g.Nx || Xbase + SEG <= 0) { seg_cnt[segi] = 0u; return; }   // no voxel of the row in this segment
     const bool has_next = s + 1 < S;
     const int64_t NyP = tomo_sign_rows_dev(g.Ny);
     const int64_t ia = ((int64_t)Z * S + s) * NyP + Y, ib = ((int64_t)Z * S + s) * NyP + Yn;
@@ -134,8 +138,9 @@ __global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__rest
         act[k] = any & ~all & vmask;
         any_nonzero |= act[k];
     }
+    seg_cnt[segi] = any_nonzero ? (u32)(__popcll(act[0]) + __popcll(act[1]) + __popcll(act[2]) + __popcll(act[3])) : 0u;
     if (any_nonzero) {
-        ulonglong2 *o = (ulonglong2 *)(seg_act + (((int64_t)Z * g.Ny + Y) * S + s) * 4);
+        ulonglong2 *o = (ulonglong2 *)(seg_act + segi * 4);
         o[0] = make_ulonglong2(act[0], act[1]);
         o[1] = make_ulonglong2(act[2], act[3]);
     }
@@ -167,18 +172,17 @@ TOMO_API int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_
 }
 
 TOMO_API int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg,
-                              unsigned long long *seg_act, void *stream)
+                              unsigned long long *seg_act, uint32_t *seg_cnt, void *stream)
 {
-    if (!signs || !seg_act || Nz < 2 || Ny < 2 || Nx < 2) return TOMO_E_ARG;
+    if (!signs || !seg_act || !seg_cnt || Nz < 2 || Ny < 2 || Nx < 2) return TOMO_E_ARG;
     if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
     int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row;
-    if (hipMemsetAsync(seg_act, 0, (size_t)nseg * 32, (hipStream_t)stream) != hipSuccess) return TOMO_E_LAUNCH;
     int64_t blocks = ceil_div64(nseg, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_classify_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const u64 *)signs, g, nseg, (u64 *)seg_act);
+                       (const u64 *)signs, g, nseg, (u64 *)seg_act, seg_cnt);
     return tomo_status();
 }
 
@@ -332,12 +336,11 @@ TOMO_API int tomo_mc_scan(const uint32_t *counts, int64_t n, uint32_t *off_a, ui
     return scan_launch(counts, nullptr, n, off_a, off_b, nz_ids, totals, workspace, workspace_bytes, stream);
 }
 
-TOMO_API int tomo_mc_scan_segments(const unsigned long long *seg_act, int64_t nseg, uint32_t *seg_aoff,
+TOMO_API int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff,
                                    uint32_t *active_segs, unsigned long long *totals, void *workspace,
                                    int64_t workspace_bytes, void *stream)
 {
-    return scan_launch(nullptr, (const u64 *)seg_act, nseg, seg_aoff, nullptr, active_segs, totals, workspace,
-                       workspace_bytes, stream);
+    return scan_launch(seg_cnt, nullptr, nseg, seg_aoff, nullptr, active_segs, totals, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------ pass 2

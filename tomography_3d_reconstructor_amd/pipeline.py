@@ -91,11 +91,12 @@ def popcount_async(vol: BitVolume) -> torch.Tensor:
     return cnt
 
 
-def close_ends(vol: BitVolume) -> BitVolume:
-    """_close_volume_ends (voxel_processor.py:56-77): fill holes of the two end slices, then the z recurrence."""
+def close_ends(vol: BitVolume, inplace: bool = False) -> BitVolume:
+    """_close_volume_ends (voxel_processor.py:56-77): fill holes of the two end slices, then the z recurrence.
+    inplace=True overwrites `vol` (for a volume the caller owns, e.g. fresh from pack) instead of copying it first."""
     nz, ny, nx = vol.shape
     L = _lib.lib()
-    out = BitVolume(vol.bits.clone(), vol.shape)
+    out = vol if inplace else BitVolume(vol.bits.clone(), vol.shape)
     wx = out.bits.shape[2]
     scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=vol.device)
     _lib.check(L.tomo_fill_holes_slice(_p(out.bits), nz, ny, nx, 0, _p(scratch), _stream()), "tomo_fill_holes_slice")
@@ -198,14 +199,15 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     # pass 1: active voxels per segment, scan, list of active segments
     if f.signs is None or f.signs_level != lvl:
         field_signs(f, lvl)
-    seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # zeroed by the call; 32-byte record per segment
-    _lib.check(L.tomo_mc_classify(_p(f.signs), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), st), "tomo_mc_classify")
+    seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # 32-byte record per NON-EMPTY segment
+    seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)       # active voxels of every segment
+    _lib.check(L.tomo_mc_classify(_p(f.signs), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
     seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     active_segs = torch.empty(nseg, dtype=torch.int32, device=dev)
     totals = torch.zeros(8, dtype=torch.int64, device=dev)
     wsb = L.tomo_mc_scan_workspace_bytes(nseg)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mc_scan_segments(_p(seg_act), nseg, _p(seg_aoff), _p(active_segs), _p(totals), _p(ws), wsb, st),
+    _lib.check(L.tomo_mc_scan_segments(_p(seg_cnt), nseg, _p(seg_aoff), _p(active_segs), _p(totals), _p(ws), wsb, st),
                "tomo_mc_scan_segments")
     na, _, nas, _ = [int(x) for x in totals[:4].cpu()]
     if na == 0:
@@ -216,7 +218,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     vox_key = torch.empty(na, dtype=torch.int64, device=dev)
     _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(active_segs), nas, _p(vox_key), st),
                "tomo_mc_list")
-    del active_segs, seg_act
+    del active_segs, seg_act, seg_cnt
     vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
     vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
     _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")

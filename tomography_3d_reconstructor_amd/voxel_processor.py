@@ -57,7 +57,7 @@ class VoxelProcessor:
         stacked = np.stack(mask_images, axis=0)
         vol = to_device_volume(stacked)
         if close_ends:
-            vol = pipeline.close_ends(vol)
+            vol = pipeline.close_ends(vol, inplace=True)     # `vol` is the fresh upload of `stacked`
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = to_host_volume(vol)
         else:

@@ -55,7 +55,8 @@ def main():
         spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
         nseg = f.Nz * f.Ny * spr
         seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)
-        t_cls = timeit(lambda: L.tomo_mc_classify(signs.data_ptr(), f.Nz, f.Ny, f.Nx, f.xorg, seg_act.data_ptr(), st))
+        seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)
+        t_cls = timeit(lambda: L.tomo_mc_classify(signs.data_ptr(), f.Nz, f.Ny, f.Nx, f.xorg, seg_act.data_ptr(), seg_cnt.data_ptr(), st))
         t_morph = timeit(lambda: pipeline.smooth(vol, 3, True))
         t_close = timeit(lambda: pipeline.close_ends(vol))
         if name != "noise50" or n <= 256:

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-stage wall time (HIP events) of one pass of the hot path on the 1024^3 ellipsoid: python tools/stagebench.py [N]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomography_3d_reconstructor_amd import pipeline  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dev = torch.device("cuda:0")
+mask = pipeline.ellipsoid_mask(n, n, n, dev).view(torch.uint8)
+depths = np.full(n, 1.0)
+stages = ["pack", "close", "smooth", "field", "mc", "finalize", "unique"]
+acc = {s: [] for s in stages}
+for it in range(6):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
+    ev[0].record()
+    vol = pipeline.pack(mask); ev[1].record()
+    vol = pipeline.close_ends(vol, inplace=True); ev[2].record()
+    vol = pipeline.smooth(vol, 3, True); ev[3].record()
+    f = pipeline.make_field(vol, True, True); ev[4].record()
+    mesh = pipeline.marching_cubes(f, 0.5); ev[5].record()
+    mesh._mc = None
+    pipeline.finalize_vertices(mesh.vpos, depths, 1.0, 1.0, True, True); ev[6].record()
+    v, fa = pipeline.ensure_manifold_mesh(mesh); ev[7].record()
+    torch.cuda.synchronize()
+    if it >= 2:
+        for k, s in enumerate(stages):
+            acc[s].append(ev[k].elapsed_time(ev[k + 1]))
+    del f, mesh, v, fa, vol
+print(" | ".join("%s %.3f" % (s, float(np.mean(acc[s]))) for s in stages), "| total %.3f ms" % sum(float(np.mean(acc[s])) for s in stages))
