@@ -78,6 +78,20 @@ int tomo_morph_pass(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, i
  * smooth_voxel_data(iterations=3, create_manifold=True) is E D | D E | D E | D E = ops 0b01010110. */
 int tomo_morph_fused(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, uint32_t ops, int nops, void *stream);
 
+/* ---------------------------------------------------------------- callers either side of the path */
+/* volume_calculator.py:23-35: counts[z] (device uint64[nz]) = np.sum(voxel_data[z]); the call zeroes counts first. */
+int tomo_slice_popcounts(const uint64_t *bits, int nz, int ny, int nx, unsigned long long *counts, void *stream);
+/* volume_calculator.py:40,62 (np.where(voxel_data) + min/max): box (device int32[6]) = {zmin, zmax, ymin, ymax, xmin,
+ * xmax} of the set voxels; an empty volume gives {INT32_MAX, -1, INT32_MAX, -1, INT32_MAX, -1}. */
+int tomo_bbox(const uint64_t *bits, int nz, int ny, int nx, int32_t *box, void *stream);
+/* image_loader.py:108 (`img >= threshold`) fused with the packing: grey = uint8 (nz, ny, nx) on the device. */
+int tomo_pack_threshold(const uint8_t *grey, uint64_t *bits, int nz, int ny, int nx, int threshold, void *stream);
+/* obj_exporter.py:17-38, byte for byte ("v %.6f %.6f %.6f" per vertex, "f a+1 b+1 c+1" per face), HOST arrays:
+ * vertices nv x 3 float32 (vertex_is_double = 0) or float64 (1), faces nf x 3 int64, 0-based.  Formats in parallel
+ * on `nthreads` host threads.  Returns 0, TOMO_E_ARG, or -errno when the file cannot be written. */
+int tomo_obj_write(const char *path, const void *vertices, int vertex_is_double, int64_t nv, const int64_t *faces,
+                   int64_t nf, int nthreads);
+
 /* ---------------------------------------------------------------- scalar field ("SDF") */
 /* bits -> extended bits (reflect of the padded array + zero pad ring), see tomo_ext_*. */
 int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx, int pad, void *stream);

@@ -255,3 +255,111 @@ def ellipsoid_masks(nz, ny, nx):
     ex = ((x - cx) / ax) ** 2
     ey = ((y - cy) / ay) ** 2
     return [(ex + ey) + ((float(z) - cz) / az) ** 2 <= 1.0 for z in range(nz)]
+
+
+# ----------------------------------------------------------------------------- the callers either side
+class VolumeCalculator:
+    """NumPy restatement of /root/reference/volume_calculator.py:10-132 (row N1), pinned by tests/golden/consumers.npz."""
+
+    def calculate_voxel_volume(self, voxel_data, mm_per_pixel_x, mm_per_pixel_y, mm_per_slice):
+        # volume_calculator.py:19-21
+        return np.sum(voxel_data) * (mm_per_pixel_x * mm_per_pixel_y * mm_per_slice)
+
+    def calculate_voxel_volume_variable_depth(self, voxel_data, mm_per_pixel_x, mm_per_pixel_y, slice_depths):
+        # volume_calculator.py:26-35: sequential accumulation over z
+        if len(slice_depths) == 0:
+            return 0.0
+        total = 0.0
+        for z in range(min(voxel_data.shape[0], len(slice_depths))):
+            total += np.sum(voxel_data[z]) * (mm_per_pixel_x * mm_per_pixel_y * slice_depths[z])
+        return total
+
+    def calculate_bounding_box(self, voxel_data, mm_per_pixel_x, mm_per_pixel_y, mm_per_slice):
+        # volume_calculator.py:40-57
+        z, y, x = np.where(voxel_data)
+        bx = (x.min() * mm_per_pixel_x, x.max() * mm_per_pixel_x)
+        by = (y.min() * mm_per_pixel_y, y.max() * mm_per_pixel_y)
+        bz = (z.min() * mm_per_slice, z.max() * mm_per_slice)
+        return {'x': bx, 'y': by, 'z': bz, 'dimensions': (bx[1] - bx[0], by[1] - by[0], bz[1] - bz[0])}
+
+    def calculate_bounding_box_variable_depth(self, voxel_data, mm_per_pixel_x, mm_per_pixel_y, slice_depths):
+        # volume_calculator.py:62-94
+        z, y, x = np.where(voxel_data)
+        if len(z) == 0 or len(slice_depths) == 0:
+            return {'x': (0, 0), 'y': (0, 0), 'z': (0, 0), 'dimensions': (0, 0, 0)}
+        bx = (x.min() * mm_per_pixel_x, x.max() * mm_per_pixel_x)
+        by = (y.min() * mm_per_pixel_y, y.max() * mm_per_pixel_y)
+        cum = np.cumsum(np.concatenate([[0], slice_depths]))
+        bz = (cum[z.min()], cum[min(z.max() + 1, len(cum) - 1)])
+        return {'x': bx, 'y': by, 'z': bz, 'dimensions': (bx[1] - bx[0], by[1] - by[0], bz[1] - bz[0])}
+
+    def calculate_density(self, volume, x_length_mm, y_length_mm, total_depth_mm):
+        return volume / (x_length_mm * y_length_mm * total_depth_mm)       # volume_calculator.py:99-100
+
+    def analyze_object_properties(self, voxel_data, processed_volume, mesh_volume, surface_area, mm_per_pixel_x,
+                                  mm_per_pixel_y, slice_depths, x_length_mm, y_length_mm, total_depth_mm):
+        # volume_calculator.py:107-132
+        vv = self.calculate_voxel_volume_variable_depth(voxel_data, mm_per_pixel_x, mm_per_pixel_y, slice_depths)
+        bb = self.calculate_bounding_box_variable_depth(voxel_data, mm_per_pixel_x, mm_per_pixel_y, slice_depths)
+        primary = mesh_volume if mesh_volume is not None else processed_volume
+        density = self.calculate_density(primary, x_length_mm, y_length_mm, np.sum(slice_depths))
+        print(f"Volume: {primary:.4f} mm³")
+        print(f"Dimensions: {bb['dimensions'][0]:.2f} x {bb['dimensions'][1]:.2f} x {bb['dimensions'][2]:.2f} mm")
+        if surface_area:
+            print(f"Surface Area: {surface_area:.4f} mm²")
+        print(f"Density: {100*density:.1f}% of total space")
+        return {'volume_mm3': primary, 'voxel_volume_mm3': vv, 'processed_voxel_volume_mm3': processed_volume,
+                'mesh_volume_mm3': mesh_volume, 'bounding_box': {'x': bb['x'], 'y': bb['y'], 'z': bb['z']},
+                'dimensions': bb['dimensions'], 'surface_area_mm2': surface_area, 'density': density}
+
+
+def obj_text(vertices, faces):
+    """The bytes /root/reference/obj_exporter.py:19-31 writes (row N4), as one str."""
+    out = ["# Tomography reconstruction model\n", f"# {len(vertices)} vertices, {len(faces)} faces\n\n"]
+    for v in vertices:
+        out.append(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
+    out.append("\n")
+    for f in faces:
+        out.append(f"f {f[0]+1} {f[1]+1} {f[2]+1}\n")
+    return "".join(out)
+
+
+def load_masks(directory, threshold=200, load_sides=(True, True, True), read_grey=None):
+    """Host restatement of /root/reference/image_loader.py:37-120 (row N2) for the loader tests: returns
+    (masks list | None, side counts, file list).  `read_grey(path)` stands for cv2.imread(path, IMREAD_GRAYSCALE)
+    (Pillow here: cv2 is absent; identical for 8-bit grey PNGs).  Parity with cv2 on colour PNGs: unpinned."""
+    import glob
+    import re
+    if read_grey is None:
+        from PIL import Image
+
+        def read_grey(p):
+            try:
+                return np.asarray(Image.open(p).convert("L"), dtype=np.uint8)
+            except Exception:
+                return None
+
+    def key(fn):
+        m = re.search(r'_(-?\d+)(?:\.(\d+))?\.png$', fn, re.IGNORECASE)
+        return (int(m.group(1)), int(m.group(2)) if m.group(2) else 0) if m else (0, 0)
+    counts, files = [0, 0, 0], []
+    for idx, side in enumerate(['Section_0', 'Section_1', 'Section_2']):
+        if not load_sides[idx]:
+            continue
+        sp = os.path.join(directory, side)
+        if not os.path.exists(sp):
+            return None, tuple(counts), files
+        fs = sorted(glob.glob(os.path.join(sp, "Mask_*.png")), key=key)
+        files.extend(fs)
+        counts[idx] = len(fs)
+    masks, first = [], None
+    for p in files:
+        img = read_grey(p)
+        if img is None:
+            continue
+        if first is None:
+            first = img
+        elif img.shape != first.shape:
+            continue
+        masks.append(img >= threshold)
+    return (masks if masks else None), tuple(counts), files

@@ -8,7 +8,8 @@ section 8c):
     PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 tests/golden/make_golden.py [--big]
 
 It imports the reference's two hot-path modules unmodified from /root/reference
-(`voxel_processor.VoxelProcessor`, `surface_extractor.SurfaceExtractor`) and
+(`voxel_processor.VoxelProcessor`, `surface_extractor.SurfaceExtractor`; for the `consumers` fixture also
+`volume_calculator.VolumeCalculator` and `obj_exporter.OBJExporter`) and
 calls them (plus, for the per-stage vectors, the exact third-party calls the
 reference makes at voxel_processor.py:62,68,88,91 and surface_extractor.py:51,55)
 on seeded inputs, then stores inputs + expected outputs as .npz / .json.  The
@@ -286,6 +287,63 @@ def gen_hashes(sizes):
         json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 
 
+def gen_consumers():
+    """Rows N1 / N4 of SURVEY.md 8(f): the reference's VolumeCalculator and OBJExporter on seeded inputs."""
+    import tempfile
+    import volume_calculator as RVC
+    import obj_exporter as ROE
+    rng = np.random.default_rng(11)
+    vc = RVC.VolumeCalculator()
+    out = {}
+    cases = []
+    for ci, (shape, sigma, thr, sides, depth) in enumerate([((20, 24, 11), 1.5, 0.5, (4, 12, 4), 6.0),
+                                                           ((9, 70, 130), 2.0, 0.52, (0, 9, 0), 3.3),
+                                                           ((16, 40, 64), 1.0, 0.45, (5, 6, 5), 10.0),
+                                                           ((6, 10, 10), 1.0, 2.0, (0, 6, 0), 1.0)]):      # last one: empty volume
+        vol = blobs(rng, shape, sigma, thr)
+        vp = RVP.VoxelProcessor()
+        vp.side_0_count, vp.side_1_count, vp.side_2_count = sides
+        depths = np.asarray(quiet(vp.calculate_slice_depths, depth), np.float64)
+        mmx, mmy, mms = 95.03 / shape[2], 143.1 / shape[1], depth / shape[0]
+        k = "c%d_" % ci
+        out[k + "vol"] = np.packbits(vol); out[k + "shape"] = np.asarray(shape, np.int64)
+        out[k + "depths"] = depths; out[k + "mm"] = np.asarray([mmx, mmy, mms], np.float64)
+        out[k + "voxel_volume"] = np.float64(vc.calculate_voxel_volume(vol, mmx, mmy, mms))
+        out[k + "voxel_volume_var"] = np.float64(vc.calculate_voxel_volume_variable_depth(vol, mmx, mmy, depths))
+        out[k + "voxel_volume_var_short"] = np.float64(vc.calculate_voxel_volume_variable_depth(vol, mmx, mmy, depths[:3]))
+        if vol.any():
+            b = vc.calculate_bounding_box(vol, mmx, mmy, mms)
+            out[k + "bbox"] = np.asarray([*b["x"], *b["y"], *b["z"], *b["dimensions"]], np.float64)
+        b = vc.calculate_bounding_box_variable_depth(vol, mmx, mmy, depths)
+        out[k + "bbox_var"] = np.asarray([*b["x"], *b["y"], *b["z"], *b["dimensions"]], np.float64)
+        out[k + "density"] = np.float64(vc.calculate_density(12.5, 95.03, 143.1, depth))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            props = vc.analyze_object_properties(vol, 3.25, None if ci % 2 else 2.75, 0.0 if ci == 2 else 7.5, mmx, mmy,
+                                                 depths, 95.03, 143.1, depth)
+        out[k + "analyze_stdout"] = np.frombuffer(buf.getvalue().encode("utf-8"), np.uint8)
+        out[k + "analyze_nums"] = np.asarray([props["volume_mm3"], props["voxel_volume_mm3"], props["density"],
+                                              *props["dimensions"]], np.float64)
+        cases.append(ci)
+    out["n_cases"] = np.int64(len(cases))
+    # OBJ export of a real (small) mesh + an empty-face mesh
+    m = run_reference_case(ellipsoid_masks(12, 20, 28), (2, 8, 2), 6.0, 143.1 / 20, 95.03 / 28)
+    oe = ROE.OBJExporter()
+    with tempfile.TemporaryDirectory() as d:
+        for name, (v, f) in {"mesh": (m["verts"], m["faces"]), "nofaces": (m["verts"][:5], np.array([]))}.items():
+            pth = os.path.join(d, name + ".obj")
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ok = oe.export_to_obj(v, f, pth)
+            out["obj_%s_verts" % name] = np.ascontiguousarray(v)
+            out["obj_%s_faces" % name] = np.ascontiguousarray(f)
+            out["obj_%s_ok" % name] = np.bool_(ok)
+            out["obj_%s_bytes" % name] = np.frombuffer(open(pth, "rb").read(), np.uint8)
+            out["obj_%s_stdout" % name] = np.frombuffer(buf.getvalue().replace(d, "<DIR>").encode("utf-8"), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "consumers.npz"), **out)
+    print("consumers:", len(cases), "volume cases,", len(m["verts"]), "vertices in the OBJ")
+
+
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     def want(n):
@@ -295,6 +353,7 @@ if __name__ == "__main__":
     if want("small"): gen_pipeline_small()
     if want("binary"): gen_binary_stages()
     if want("cfg1"): gen_ellipsoid_cfg1()
+    if want("consumers"): gen_consumers()
     if want("hashes"):
         sizes = [(64, 128, 128), (96, 80, 112), (256, 256, 256)]
         if "--big" in sys.argv:

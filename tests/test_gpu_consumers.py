@@ -1,0 +1,152 @@
+"""GPU tier for the rows either side of the hot path: VolumeCalculator on the resident bit volume,
+ImageLoader with the fused threshold + pack upload, and the orchestrator's call sequence
+(tomography_3d_reconstruction.py:271-323) replayed against the drop-in classes -- all against the fixtures generated
+from the reference and the CPU oracle."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tomography_3d_reconstructor_amd import _devcache, pipeline
+from tomography_3d_reconstructor_amd import SurfaceExtractor, VoxelProcessor
+from tomography_3d_reconstructor_amd.image_loader import ImageLoader
+from tomography_3d_reconstructor_amd.obj_exporter import OBJExporter
+from tomography_3d_reconstructor_amd.volume_calculator import VolumeCalculator
+from test_consumers_cpu import G, check_volume_calculator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("ci", range(int(G["n_cases"])))
+def test_volume_calculator_matches_reference(dev, ci):
+    check_volume_calculator(VolumeCalculator(), ci)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7), (7, 33, 130), (65, 16, 64), (2, 1, 1), (5, 40, 1100)])
+def test_slice_counts_and_bbox(dev, shape):
+    rng = np.random.default_rng(3)
+    a = rng.random(shape) < 0.3
+    a[:, :, : shape[2] // 3] = False
+    a[0] = False
+    vol = pipeline.pack(torch.from_numpy(a.view(np.uint8)).to(dev))
+    assert np.array_equal(pipeline.slice_counts(vol).cpu().numpy(), a.reshape(shape[0], -1).sum(1))
+    z, y, x = np.where(a)
+    exp = None if len(z) == 0 else (z.min(), z.max(), y.min(), y.max(), x.min(), x.max())
+    assert pipeline.bounding_box(vol) == (None if exp is None else tuple(int(v) for v in exp))
+    empty = pipeline.pack(torch.zeros(shape, dtype=torch.uint8, device=dev))
+    assert pipeline.bounding_box(empty) is None and int(pipeline.slice_counts(empty).sum()) == 0
+
+
+@pytest.mark.parametrize("shape,thr", [((3, 5, 7), 200), ((4, 9, 64), 0), ((2, 17, 130), 255), ((3, 8, 1024), 128),
+                                       ((2, 4, 48), 256), ((2, 3, 1100), 1)])
+def test_pack_threshold(dev, shape, thr):
+    rng = np.random.default_rng(4)
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    g[0, 0, :3] = [thr - 1 if thr > 0 else 0, min(thr, 255), min(thr + 1, 255)]
+    vol = pipeline.pack_threshold(torch.from_numpy(g).to(dev), thr)
+    assert np.array_equal(pipeline.unpack(vol).cpu().numpy(), g >= thr)
+
+
+def write_stack(root, masks_u8, sides):
+    from PIL import Image
+    k = 0
+    for si, n in enumerate(sides):
+        os.makedirs(os.path.join(root, "Section_%d" % si), exist_ok=True)
+        for j in range(n):
+            # descending / negative numbering on side 0, like the reference's generator produces (simple_generator.py)
+            num = (j - n) if si == 0 else j + 1
+            Image.fromarray(masks_u8[k], mode="L").save(os.path.join(root, "Section_%d" % si, "Mask_Patient_%d.png" % num))
+            k += 1
+
+
+def test_image_loader_matches_host_restatement_and_feeds_the_device(dev, tmp_path):
+    nz, ny, nx = 20, 48, 80
+    sides = (4, 12, 4)
+    rng = np.random.default_rng(6)
+    masks = np.stack(O.ellipsoid_masks(nz, ny, nx))
+    grey = np.where(masks, 255, 0).astype(np.uint8)
+    grey[rng.random(grey.shape) < 0.05] = rng.integers(150, 256, int((rng.random(grey.shape) < 0.05).sum()) or 1)[0]
+    write_stack(str(tmp_path), grey, sides)
+    exp, counts, files = O.load_masks(str(tmp_path), 200)
+    ld = ImageLoader()
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        assert ld.load_mask_images(str(tmp_path), 200, [True, True, True]) is True
+    assert "Found masks - Side_0: 4, Side_1: 12, Side_2: 4" in out.getvalue()
+    assert ld.get_side_counts() == counts == sides and ld.get_num_slices() == nz
+    assert ld.get_image_dimensions() == (nx, ny) and ld.mask_files == files
+    got = ld.get_mask_images()
+    assert len(got) == nz and all(m.dtype == np.bool_ and np.array_equal(m, e) for m, e in zip(got, exp))
+    # the packed volume is already on the device: create_voxel_data must not upload (cache hit through the views' base)
+    base = got[0].base
+    cached = _devcache.get(base)
+    assert cached is not None and np.array_equal(pipeline.unpack(cached).cpu().numpy(), np.stack(exp))
+    vp, ovp = VoxelProcessor(), O.VoxelProcessor()
+    with contextlib.redirect_stdout(io.StringIO()):
+        created = vp.create_voxel_data(got, True, *sides)
+        ocreated = ovp.create_voxel_data(exp, True, *sides)
+    assert np.array_equal(created, ocreated)
+    assert np.array_equal(pipeline.unpack(_devcache.get(base)).cpu().numpy(), np.stack(exp)), "loader volume was overwritten"
+    # missing folder / disabled sides, as the reference reports them
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        assert ImageLoader().load_mask_images(str(tmp_path / "nowhere"), 200) is False
+    assert "Folder Section_0 not found" in out.getvalue()
+    ld2 = ImageLoader()
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert ld2.load_mask_images(str(tmp_path), 200, [False, True, False]) is True
+    assert ld2.get_side_counts() == (0, 12, 0) and ld2.get_num_slices() == 12
+
+
+def test_orchestrator_sequence_end_to_end(dev, tmp_path):
+    """main() of the reference (tomography_3d_reconstruction.py:271-323) as a call sequence: load -> create ->
+    depths -> volumes (raw / smoothed) -> mesh volume -> surface area -> analyse -> OBJ; drop-in classes vs the CPU
+    oracle on the same PNG stack (config 1 of BASELINE.json: 128x128x64 half-ellipsoid-like stack)."""
+    nz, ny, nx = 64, 128, 128
+    sides = (8, 48, 8)
+    x_mm, y_mm, depth_mm = 95.03, 143.1, 6.0
+    masks = np.stack(O.ellipsoid_masks(nz, ny, nx))
+    write_stack(str(tmp_path), np.where(masks, 255, 0).astype(np.uint8), sides)
+    ld = ImageLoader()
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert ld.load_mask_images(str(tmp_path), 200, [True, True, True])
+    w, h = ld.get_image_dimensions()
+    mmx, mmy = x_mm / w, y_mm / h
+    omasks, _, _ = O.load_masks(str(tmp_path), 200)
+
+    def run(vp, se, vc, mask_list):
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            vol = vp.create_voxel_data(mask_list, True, *sides)
+            depths = vp.calculate_slice_depths(depth_mm)
+            raw = vc.calculate_voxel_volume_variable_depth(vol, mmx, mmy, depths)
+            sm = vp.smooth_voxel_data(vol, iterations=3, create_manifold=True)
+            proc = vc.calculate_voxel_volume_variable_depth(sm, mmx, mmy, depths)
+            v, f = se.extract_manifold_surface(sm, depths, mmy, mmx, smooth=True, manifold=True, add_padding=True)
+            mv = se.calculate_mesh_volume(v, f)
+            area = se.calculate_surface_area(v, f)
+            props = vc.analyze_object_properties(vol, proc, mv, area, mmx, mmy, depths, x_mm, y_mm, depth_mm)
+        return vol, depths, raw, sm, proc, v, f, mv, area, props, out.getvalue()
+
+    a = run(VoxelProcessor(), SurfaceExtractor(), VolumeCalculator(), ld.get_mask_images())
+    b = run(O.VoxelProcessor(), O.SurfaceExtractor(), O.VolumeCalculator(), omasks)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    assert np.float64(a[2]).tobytes() == np.float64(b[2]).tobytes() and np.float64(a[4]).tobytes() == np.float64(b[4]).tobytes()
+    assert a[5].dtype == np.float32 and a[5].tobytes() == b[5].tobytes() and a[6].dtype == np.int64 and np.array_equal(a[6], b[6])
+    assert abs(a[7] - b[7]) <= 1e-6 * abs(b[7]) and abs(float(a[8]) - float(b[8])) <= 1e-5 * abs(float(b[8]))   # tree reductions
+    assert a[9]["dimensions"] == b[9]["dimensions"] and a[9]["voxel_volume_mm3"] == b[9]["voxel_volume_mm3"]
+    assert a[10].splitlines()[:3] == b[10].splitlines()[:3]          # Voxels / Slice depth / Surface lines
+    # mesh volume agrees with the voxel volume to the survey's sanity band (1e-3 relative)
+    assert abs(a[7] - a[4]) <= 2e-3 * a[4]
+    pth = str(tmp_path / "model.obj")
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert OBJExporter().export_to_obj(a[5], a[6], pth)
+    assert open(pth).read() == O.obj_text(b[5], b[6])

@@ -35,6 +35,10 @@ SIGNATURES = {
     "tomo_pack_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "tomo_unpack_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     "tomo_popcount": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "tomo_slice_popcounts": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "tomo_bbox": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "tomo_pack_threshold": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    "tomo_obj_write": (_c_i, [ctypes.c_char_p, _c_p, _c_i, _c_i64, _c_p, _c_i64, _c_i]),
     "tomo_fill_holes_slice": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_close_ends_workspace_words": (_c_i64, [_c_i, _c_i, _c_i]),
     "tomo_close_ends_scan": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),

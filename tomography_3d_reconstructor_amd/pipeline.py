@@ -91,6 +91,36 @@ def popcount_async(vol: BitVolume) -> torch.Tensor:
     return cnt
 
 
+def pack_threshold(grey: torch.Tensor, threshold: int) -> BitVolume:
+    """`img >= threshold` (image_loader.py:108) of a device uint8 (nz, ny, nx) grey stack, straight to a BitVolume."""
+    if grey.dim() != 3 or grey.dtype != torch.uint8:
+        raise TypeError("grey stack must be uint8 (nz, ny, nx)")
+    grey = grey.contiguous()
+    nz, ny, nx = grey.shape
+    L = _lib.lib()
+    bits = torch.empty((nz, ny, L.tomo_words_per_row(nx)), dtype=torch.int64, device=grey.device)
+    _lib.check(L.tomo_pack_threshold(_p(grey), _p(bits), nz, ny, nx, int(threshold), _stream()), "tomo_pack_threshold")
+    return BitVolume(bits, (nz, ny, nx))
+
+
+def slice_counts(vol: BitVolume) -> torch.Tensor:
+    """np.sum(voxel_data[z]) for every z (volume_calculator.py:33) -> int64 (nz,) device tensor."""
+    nz, ny, nx = vol.shape
+    counts = torch.empty(nz, dtype=torch.int64, device=vol.device)
+    _lib.check(_lib.lib().tomo_slice_popcounts(_p(vol.bits), nz, ny, nx, _p(counts), _stream()), "tomo_slice_popcounts")
+    return counts
+
+
+def bounding_box(vol: BitVolume):
+    """min / max of np.where(voxel_data) per axis (volume_calculator.py:40-44, 62-72) -> (zmin, zmax, ymin, ymax,
+    xmin, xmax) as Python ints, or None for an empty volume."""
+    nz, ny, nx = vol.shape
+    box = torch.empty(6, dtype=torch.int32, device=vol.device)
+    _lib.check(_lib.lib().tomo_bbox(_p(vol.bits), nz, ny, nx, _p(box), _stream()), "tomo_bbox")
+    b = [int(x) for x in box.cpu()]
+    return None if b[1] < 0 else tuple(b)
+
+
 def close_ends(vol: BitVolume, inplace: bool = False) -> BitVolume:
     """_close_volume_ends (voxel_processor.py:56-77): fill holes of the two end slices, then the z recurrence.
     inplace=True overwrites `vol` (for a volume the caller owns, e.g. fresh from pack) instead of copying it first."""

@@ -37,6 +37,22 @@ def to_host_volume(vol):
     return out
 
 
+def _common_base(mask_images):
+    """If the masks are the consecutive slices (views) of ONE contiguous (nz, ny, nx) array -- what this package's
+    ImageLoader hands out -- return that array: np.stack would only copy it."""
+    first = mask_images[0]
+    base = getattr(first, "base", None)
+    if not (isinstance(first, np.ndarray) and isinstance(base, np.ndarray) and base.ndim == 3 and
+            base.shape[0] == len(mask_images) and base.flags.c_contiguous and base.dtype == first.dtype):
+        return None
+    ptr0, step = base.__array_interface__["data"][0], base.strides[0]
+    for i, m in enumerate(mask_images):
+        if not (isinstance(m, np.ndarray) and m.base is base and m.shape == base.shape[1:] and
+                m.strides == base.strides[1:] and m.__array_interface__["data"][0] == ptr0 + i * step):
+            return None
+    return base
+
+
 class VoxelProcessor:
     """Handles voxel data creation and processing operations (reference: voxel_processor.py:27)."""
 
@@ -54,13 +70,19 @@ class VoxelProcessor:
         self.side_0_count = side_0_count
         self.side_1_count = side_1_count
         self.side_2_count = side_2_count
-        stacked = np.stack(mask_images, axis=0)
-        vol = to_device_volume(stacked)
+        base = _common_base(mask_images)
+        cached = _devcache.get(base) if base is not None else None
         if close_ends:
-            vol = pipeline.close_ends(vol, inplace=True)     # `vol` is the fresh upload of `stacked`
+            if cached is not None:                           # uploaded (and thresholded) by ImageLoader already
+                vol = pipeline.close_ends(cached)
+            else:
+                stacked = base if base is not None else np.stack(mask_images, axis=0)
+                vol = pipeline.close_ends(to_device_volume(stacked), inplace=True)    # a fresh upload: ours to overwrite
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = to_host_volume(vol)
         else:
+            stacked = np.stack(mask_images, axis=0)          # the reference returns a new array here
+            vol = cached if cached is not None else to_device_volume(stacked)
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = stacked
             _devcache.put(stacked, vol)
