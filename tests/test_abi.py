@@ -71,3 +71,20 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                     text = open(os.path.join(dirpath, f)).read()
                     assert not bad.search(text), "product file references the oracle: " + os.path.join(dirpath, f)
+
+
+def test_devcache_fingerprint_handles_large_and_small_arrays():
+    """The device-side cache key of a host volume (identity + sampled checksum): any size, edits noticed."""
+    import numpy as np
+    from tomography_3d_reconstructor_amd import _devcache
+    for shape in [(2, 3, 5), (64, 128, 128), (7, 333, 129)]:
+        a = np.zeros(shape, bool)
+        f0 = _devcache._fingerprint(a)
+        a.reshape(-1)[0] = True
+        assert _devcache._fingerprint(a) != f0
+    v = object()
+    big = np.ones((70, 100, 100), bool)
+    _devcache.put(big, v)
+    assert _devcache.get(big) is v
+    big[:] = False
+    assert _devcache.get(big) is None

@@ -20,7 +20,7 @@ def _fingerprint(arr):
     flat = a.reshape(-1).view(np.uint8)
     n = flat.size
     step = max(1, n // 65536)
-    sample = flat[::step]
+    sample = np.ascontiguousarray(flat[::step])      # contiguous: it is re-viewed as uint64 below
     return (arr.__array_interface__["data"][0], arr.shape, arr.strides, str(arr.dtype),
             int(sample.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(sample[: (sample.size // 8) * 8].view(np.uint64)))
             if sample.size >= 8 else 0)
