@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import pipeline
-from .voxel_processor import _device, to_device_volume
+from .voxel_processor import _device, to_device_volume, to_host_array
 
 
 class SurfaceExtractor:
@@ -29,8 +29,8 @@ class SurfaceExtractor:
         if res is None:
             return None
         verts, faces = res
-        vertices = verts.cpu().numpy()
-        faces_np = faces.cpu().numpy()
+        vertices = to_host_array(verts.contiguous())
+        faces_np = to_host_array(faces.contiguous())
         if len(faces_np) == 0:
             faces_np = np.array([])
         print(f"Surface: {len(vertices)} vertices, {len(faces_np)} faces")
