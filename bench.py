@@ -171,10 +171,10 @@ def main():
         alg = 5.0 * timer.padded_voxels              # 1 B mask + 4 B field per padded voxel of the launch (rank 0)
         ach = alg / (fms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc.json")   # written by tools/profile_round.sh
         if not dist and os.path.exists(pmc) and (nz, ny, nx) == (1024, 1024, 1024):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]   # separate rocprofv3 --pmc passes of this command
-        roofline = {"bound": "hbm", "kernel": "field_gauss_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "field_tile_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes": alg, "kernel_ms": round(fms, 4)}
     nverts = int(res[0].shape[0]) if res else 0

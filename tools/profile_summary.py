@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/profile_round.sh into the files kept under profiles/:
+<tag>_bench_kernel_stats.csv, <tag>_field_pmc.json, <tag>_bench_profile.md."""
+import collections, csv, glob, json, os, shutil, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+PASSES = 7            # --steps 5 --warmup 2
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(out, pattern), recursive=True)
+    return f[0] if f else None
+
+
+def last_json(path):
+    for line in reversed(open(path).read().splitlines()):
+        if line.startswith("{"):
+            return line
+    return ""
+
+
+trace = one("trace/**/*kernel_trace.csv")
+acc = collections.OrderedDict()
+for r in csv.DictReader(open(trace)):
+    acc.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+tot = sum(sum(v) for v in acc.values())
+stats = one("trace/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(out, "%s_bench_kernel_stats.csv" % tag))
+
+
+def pmc(sub, name):
+    f = one(sub + "/**/*counter_collection.csv")
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+
+
+def find(d, sub):
+    for k, v in d.items():
+        if sub in k:
+            return v
+    return None
+
+
+fk = "field_tile_kernel"
+fkb, wkb = find(fetch, fk), find(write, fk)
+field_us = [sum(v) / len(v) for k, v in acc.items() if fk in k][0]
+pmcj = {"kernel": fk, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+        "fetch_size_kb_raw": fkb, "write_size_kb": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024,
+        "correction": "reads x2 (gfx950 FETCH_SIZE counts half of the bytes of coalesced reads; calibrated on pack16_kernel's "
+                      "exact 1 GiB), writes exact", "kernel_us_in_trace": field_us}
+json.dump(pmcj, open(os.path.join(out, "%s_field_pmc.json" % tag), "w"), indent=1)
+
+md = ["# Round profile `%s` -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`\n" % tag,
+      "MI355X (gfx950), 1024^3 ellipsoid, 7 passes of the hot path (2 warm-up + 5 timed).  Full CSV: `%s_bench_kernel_stats.csv`.\n" % tag,
+      "Bench line of the profiled run: `%s`\n" % last_json(os.path.join(out, "bench_trace.log")),
+      "Bench line, un-profiled (`python bench.py`): `%s`\n" % last_json(os.path.join(out, "bench_plain.log")),
+      "\n| kernel | calls | avg us | ms per pass | % |\n|---|---|---|---|---|"]
+for n, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    md.append("| `%s` | %d | %.2f | %.3f | %.2f |" % (n[:70], len(v), sum(v) / len(v), sum(v) / PASSES / 1e3, 100 * sum(v) / tot))
+md.append("\n(`at::native::*` kernels are the synthetic-mask generation before the timed region.)\n")
+md.append("\n## PMC passes (separate runs of the same command: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`), per dispatch, KB\n")
+md.append("Calibration: `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
+          "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below.  WRITE_SIZE is exact.\n")
+md.append("| kernel | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM bytes = 2*FETCH + WRITE |\n|---|---|---|---|")
+for sub in ("pack16_kernel", "morph_fused_kernel", "extend_kernel", fk, "mc_classify_bits_kernel", "mc_emit_kernel"):
+    a, b = find(fetch, sub), find(write, sub)
+    if a is not None and b is not None:
+        md.append("| `%s` | %.0f | %.0f | %.3e |" % (sub, a, b, (2 * a + b) * 1024))
+alg = 5.0 * 1026 ** 3
+md.append("\nField (\"SDF\") kernel `%s`: avg %.1f us per launch in this trace -> algorithmic 5 B x 1026^3 = %.3e B / launch = %.0f GB/s "
+          "= %.1f %% of the 8 TB/s HBM3E peak; measured HBM traffic %.3e B per launch.\n"
+          % (fk, field_us, alg, alg / field_us / 1e3, alg / field_us / 1e3 / 80.0, pmcj["hbm_bytes_per_launch"]))
+open(os.path.join(out, "%s_bench_profile.md" % tag), "w").write("\n".join(md))
+print("\n".join(md[-3:]))
