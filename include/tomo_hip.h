@@ -99,19 +99,21 @@ int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx
  * gaussian_filter(sigma=0.5) (three 5-tap float64 correlate1d passes, axis 0,1,2, mode reflect),
  * cast to float32.  gaussian = 0 writes the raw 0/1 field (manifold=False). */
 int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
-                    unsigned long long *signs, void *stream);   /* `field` must be 128-byte aligned */
+                    unsigned long long *signs, uint8_t *gcls, void *stream);   /* `field` must be 128-byte aligned */
 /* Sign records (input of marching-cubes pass 1): uint64 [Nz][S][NyP][4], S = tomo_mc_segments_per_row(Nx, xorg),
  * NyP = tomo_sign_rows(Ny) (Ny rounded up to 16 so that 16-row groups of records are 512-byte aligned);
  * bit L of word k of record (Z, s, Y) = [field(Z, Y, column 256 s - 224 + 4 L + k) > iso].  tomo_field_fill writes
- * them as a by-product (iso 0.5), for every row Y < Ny of every segment, when `signs` is not NULL and gaussian = 1
- * (no zeroing needed; bits of columns outside the padded row are unspecified and ignored by tomo_mc_classify);
- * tomo_field_signs derives them from any float field for slices [z_begin, z_end). */
+ * them as a by-product (iso 0.5) when `signs` is not NULL and gaussian = 1 (no zeroing needed; bits of columns outside
+ * the padded row are unspecified and ignored by tomo_mc_classify).  Records come in GROUPS of 16 rows; gcls
+ * (uint8 [Nz][NyP / 16][S], always passed together with signs) holds the class of every group: 0 / 1 = all bits 0 / 1
+ * and the 16 records are NOT stored (70 % of the groups of an ellipsoid volume), 2 = the records are stored.
+ * tomo_field_signs derives records from any float field for slices [z_begin, z_end) (all groups of class 2). */
 int64_t tomo_sign_rows(int Ny);
 int tomo_field_signs_fused(int nx);                      /* 1: tomo_field_fill writes the records itself (always, ABI 2) */
 /* Size (uint64 words) of the buffer passed as `signs` to tomo_field_fill. */
 int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg);
 int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso, int z_begin,
-                     int z_end, unsigned long long *signs, void *stream);
+                     int z_end, unsigned long long *signs, uint8_t *gcls, void *stream);
 
 /* ---------------------------------------------------------------- marching cubes (Lewiner MC33) */
 /* skimage.measure.marching_cubes(volume, level) (surface_extractor.py:55) as five device passes.
@@ -126,8 +128,8 @@ int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, 
  *    seg = (Z*Ny + Y)*S + s) and, for every NON-EMPTY segment, seg_act[4*seg + k] = 64-bit mask whose bit L says
  *    voxel 4L+k of the segment (X = 256 s - 224 + 4L + k - xorg) is active (seg_act: uint64[4*nseg]; records of
  *    empty segments stay unwritten and are never read).  No float is read. */
-int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg, unsigned long long *seg_act,
-                     uint32_t *seg_cnt, void *stream);
+int tomo_mc_classify(const unsigned long long *signs, const uint8_t *gcls, int Nz, int Ny, int Nx, int xorg,
+                     unsigned long long *seg_act, uint32_t *seg_cnt, void *stream);
 /* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of seg_cnt, active_segs uint32[nseg] = indices
  * of the non-empty segments in order, totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */
 int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff, uint32_t *active_segs,

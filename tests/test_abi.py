@@ -49,7 +49,7 @@ def test_argument_checks_do_not_need_a_gpu():
     L = _lib.lib()
     assert L.tomo_pack_bits(None, None, 1, 1, 1, None) == -1
     assert L.tomo_morph_pass(None, None, 4, 4, 4, 0, None) == -1
-    assert L.tomo_mc_classify(None, 4, 4, 4, 0, None, None, None) == -1
+    assert L.tomo_mc_classify(None, None, 4, 4, 4, 0, None, None, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -49,6 +49,8 @@ struct FieldParams {
     int64_t pitch;
     int nxc, ntr, nzg;              // blocks per row, tile rows, slice groups
     u64 *signs;                     // sign records [Nz][S][NyP][4] (may be null)
+    unsigned char *gcls;            // class of every group of 16 rows of records [Nz][NyP / 16][S]: 0 / 1 = all bits 0 / 1
+                                    // (records not written), 2 = records written
     int S, NyP;
     int SB;                         // bytes per (slice, row, word k) line of the LDS sign area: tiles + 7, rounded up to 8
 };
@@ -272,14 +274,19 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
             const int z = it / nsegl, sl = it - z * nsegl;
             const int Z = Z0 + z, s = s0 + sl;
             if (Z >= p.Nz || s >= p.S) continue;
-            u64 cm = 0ull, mm = 0ull;
+            u64 cm = 0ull, mm = 0ull, vm = 0ull;
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 const int jl = 8 * sl + b - joff;
                 const int c = (jl >= 0 && jl < nt) ? s_cls[z][jl] : 3;
                 if (c == 1) cm |= 0xffull << (8 * b);
                 if (c == 2) mm |= 0xffull << (8 * b);
+                if (c != 3) vm |= 0xffull << (8 * b);
             }
+            // a group whose tiles are all constant and equal needs no records: marching cubes reads its class instead
+            const int gc = mm ? 2 : (cm == 0ull ? 0 : (cm == vm ? 1 : 2));
+            if (lane == 0) p.gcls[((int64_t)Z * (p.NyP >> 4) + tr) * p.S + s] = (unsigned char)gc;
+            if (gc != 2) continue;
             const u64 v = cm | (*(const u64 *)(s_sign + ((z * FT_ROWS + r) * 4 + k) * SB + 8 * sl) & mm);
             if (r < nrows) p.signs[((((int64_t)Z * p.S + s) * p.NyP) + Y0 + r) * 4 + k] = v;
         }
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void field_raw_kernel(const u64 *__restrict__ 
     field[((int64_t)Z * Ny + Y) * pitch + xorg + X] = (float)((w >> (e & 63)) & 1ull);
 }
 
-static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs)
+static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs, unsigned char *gcls)
 {
     p.Nz = nz + 2 * pad; p.Ny = ny + 2 * pad;
     const int Nx = nx + 2 * pad;
@@ -316,6 +323,7 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.S = (int)tomo_mc_segments_per_row(Nx, tomo_field_xorg(pad));
     p.NyP = (int)tomo_sign_rows(p.Ny);
     p.signs = (u64 *)signs;
+    p.gcls = gcls;
     int ntmax = p.NT < FT_MAXT ? p.NT : FT_MAXT;     // tiles of the widest block
     int WS = ntmax + 1;
     size_t words = (((size_t)(FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~(size_t)1);
@@ -336,12 +344,13 @@ TOMO_API int64_t tomo_sign_buffer_words(int Nz, int Ny, int Nx, int xorg)
 }
 
 TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
-                             unsigned long long *signs, void *stream)
+                             unsigned long long *signs, uint8_t *gcls, void *stream)
 {
-    if (!ext || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1)) return TOMO_E_ARG;
+    if (!ext || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1) || ((signs != nullptr) != (gcls != nullptr)))
+        return TOMO_E_ARG;
     if (((uintptr_t)field & 127u) != 0) return TOMO_E_ARG;
     FieldParams p;
-    size_t lds = fill_params(p, nz, ny, nx, pad, gaussian ? signs : nullptr);
+    size_t lds = fill_params(p, nz, ny, nx, pad, gaussian ? signs : nullptr, gaussian ? gcls : nullptr);
     hipStream_t s = (hipStream_t)stream;
     if (!gaussian) {
         const int Nx = nx + 2 * pad;

@@ -87,7 +87,16 @@ __device__ static inline Rec4 load_rec(const u64 *__restrict__ signs, int64_t id
     return r;
 }
 
-__global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__restrict__ signs, const McGrid g,
+__device__ static inline Rec4 rec_of(const u64 *__restrict__ signs, int64_t idx, int gc)
+{   // record idx of a group of class gc: all zero / all one without touching memory, or the stored record
+    if (gc == 2) return load_rec(signs, idx);
+    Rec4 r;
+    r.b[0] = r.b[1] = r.b[2] = r.b[3] = gc ? ~0ull : 0ull;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__restrict__ signs,
+                                                               const unsigned char *__restrict__ gcls, const McGrid g,
                                                                int64_t ntasks, u64 *__restrict__ seg_act,
                                                                u32 *__restrict__ seg_cnt)
 {
@@ -106,12 +115,23 @@ __global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__rest
     const int64_t NyP = tomo_sign_rows_dev(g.Ny);
     const int64_t ia = ((int64_t)Z * S + s) * NyP + Y, ib = ((int64_t)Z * S + s) * NyP + Yn;
     const int64_t ic = ((int64_t)Z1 * S + s) * NyP + Y, id = ((int64_t)Z1 * S + s) * NyP + Yn;
-    Rec4 R[4] = {load_rec(signs, ia), load_rec(signs, ib), load_rec(signs, ic), load_rec(signs, id)};
+    // classes of the four 16-row groups of records involved (and of their right neighbours): 0 / 1 = constant, no records
+    const int64_t G = NyP >> 4;
+    const int64_t qa = ((int64_t)Z * G + (Y >> 4)) * S + s, qb = ((int64_t)Z * G + (Yn >> 4)) * S + s;
+    const int64_t qc = ((int64_t)Z1 * G + (Y >> 4)) * S + s, qd = ((int64_t)Z1 * G + (Yn >> 4)) * S + s;
+    const int ga = gcls[qa], gb = gcls[qb], gc = gcls[qc], gd = gcls[qd];
+    const int na = has_next ? gcls[qa + 1] : ga, nb = has_next ? gcls[qb + 1] : gb;
+    const int nc = has_next ? gcls[qc + 1] : gc, nd = has_next ? gcls[qd + 1] : gd;
+    if (ga != 2 && ga == gb && ga == gc && ga == gd && na == ga && nb == ga && nc == ga && nd == ga) {
+        seg_cnt[segi] = 0u;                              // the whole neighbourhood has one sign
+        return;
+    }
+    Rec4 R[4] = {rec_of(signs, ia, ga), rec_of(signs, ib, gb), rec_of(signs, ic, gc), rec_of(signs, id, gd)};
     u64 nx0[4];                                          // first column of the next segment, same rows
-    nx0[0] = has_next ? signs[(ia + NyP) * 4] & 1ull : 0ull;
-    nx0[1] = has_next ? signs[(ib + NyP) * 4] & 1ull : 0ull;
-    nx0[2] = has_next ? signs[(ic + NyP) * 4] & 1ull : 0ull;
-    nx0[3] = has_next ? signs[(id + NyP) * 4] & 1ull : 0ull;
+    nx0[0] = has_next ? (na == 2 ? signs[(ia + NyP) * 4] & 1ull : (u64)na) : 0ull;
+    nx0[1] = has_next ? (nb == 2 ? signs[(ib + NyP) * 4] & 1ull : (u64)nb) : 0ull;
+    nx0[2] = has_next ? (nc == 2 ? signs[(ic + NyP) * 4] & 1ull : (u64)nc) : 0ull;
+    nx0[3] = has_next ? (nd == 2 ? signs[(id + NyP) * 4] & 1ull : (u64)nd) : 0ull;
     // per element k: which lanes hold an existing voxel, and which lane holds the last voxel X = Nx-1 (its
     // x+1 neighbour is clamped to itself)
     u64 act[4];
@@ -156,12 +176,18 @@ static inline int make_grid(McGrid &g, const float *field, int Nz, int Ny, int N
 }
 
 TOMO_API int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                              int z_begin, int z_end, unsigned long long *signs, void *stream)
+                              int z_begin, int z_end, unsigned long long *signs, uint8_t *gcls, void *stream)
 {
     McGrid g;
     int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
     if (rc) return rc;
-    if (!signs || z_begin < 0 || z_end > Nz || z_begin > z_end) return TOMO_E_ARG;
+    if (!signs || !gcls || z_begin < 0 || z_end > Nz || z_begin > z_end) return TOMO_E_ARG;
+    {   // every group of these slices has stored records
+        const int64_t per_slice = (tomo_sign_rows(Ny) >> 4) * g.segs_per_row;
+        if (z_end > z_begin && hipMemsetAsync(gcls + z_begin * per_slice, 2, (size_t)((z_end - z_begin) * per_slice),
+                                              (hipStream_t)stream) != hipSuccess)
+            return TOMO_E_LAUNCH;
+    }
     int64_t ntasks = (int64_t)(z_end - z_begin) * g.segs_per_row * Ny;
     if (ntasks == 0) return TOMO_OK;
     int64_t blocks = ceil_div64(ntasks, 4);
@@ -171,10 +197,10 @@ TOMO_API int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_
     return tomo_status();
 }
 
-TOMO_API int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, int Nx, int xorg,
+TOMO_API int tomo_mc_classify(const unsigned long long *signs, const uint8_t *gcls, int Nz, int Ny, int Nx, int xorg,
                               unsigned long long *seg_act, uint32_t *seg_cnt, void *stream)
 {
-    if (!signs || !seg_act || !seg_cnt || Nz < 2 || Ny < 2 || Nx < 2) return TOMO_E_ARG;
+    if (!signs || !gcls || !seg_act || !seg_cnt || Nz < 2 || Ny < 2 || Nx < 2) return TOMO_E_ARG;
     if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
@@ -182,7 +208,7 @@ TOMO_API int tomo_mc_classify(const unsigned long long *signs, int Nz, int Ny, i
     int64_t blocks = ceil_div64(nseg, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_classify_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const u64 *)signs, g, nseg, (u64 *)seg_act, seg_cnt);
+                       (const u64 *)signs, gcls, g, nseg, (u64 *)seg_act, seg_cnt);
     return tomo_status();
 }
 

@@ -45,6 +45,7 @@ class Field:
     xorg: int
     signs: torch.Tensor = None     # sign records (Nz, S, NyP, 4) int64 for `signs_level`, or None
     signs_level: float = 0.5
+    gcls: torch.Tensor = None      # class of every 16-row group of records (Nz, NyP / 16, S) uint8: 0 / 1 constant, 2 stored
 
     def dense(self):
         return self.data[:, :, self.xorg:self.xorg + self.Nx]
@@ -179,13 +180,15 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
     fused = bool(manifold) and bool(L.tomo_field_signs_fused(nx))
     signs = None
     sbuf = None
+    gcls = None
     if fused:
         S, NyP = L.tomo_mc_segments_per_row(Nx, xorg), L.tomo_sign_rows(Ny)
         sbuf = torch.empty(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
         signs = sbuf[: Nz * S * NyP * 4].view(Nz, S, NyP, 4)
-    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _stream()),
+        gcls = torch.empty((Nz, NyP // 16, S), dtype=torch.uint8, device=vol.device)
+    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _p(gcls), _stream()),
                "tomo_field_fill")
-    return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5)
+    return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5, gcls)
 
 
 def field_signs(f: Field, level: float, z_begin: int = 0, z_end: int = None):
@@ -193,10 +196,11 @@ def field_signs(f: Field, level: float, z_begin: int = 0, z_end: int = None):
     L = _lib.lib()
     z_end = f.Nz if z_end is None else z_end
     if f.signs is None:
-        f.signs = torch.empty((f.Nz, L.tomo_mc_segments_per_row(f.Nx, f.xorg), L.tomo_sign_rows(f.Ny), 4),
-                              dtype=torch.int64, device=f.data.device)
+        S, NyP = L.tomo_mc_segments_per_row(f.Nx, f.xorg), L.tomo_sign_rows(f.Ny)
+        f.signs = torch.empty((f.Nz, S, NyP, 4), dtype=torch.int64, device=f.data.device)
+        f.gcls = torch.empty((f.Nz, NyP // 16, S), dtype=torch.uint8, device=f.data.device)
     _lib.check(L.tomo_field_signs(_p(f.data), f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, float(level), z_begin, z_end,
-                                  _p(f.signs), _stream()), "tomo_field_signs")
+                                  _p(f.signs), _p(f.gcls), _stream()), "tomo_field_signs")
     f.signs_level = float(level)
     return f.signs
 
@@ -231,7 +235,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
         field_signs(f, lvl)
     seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # 32-byte record per NON-EMPTY segment
     seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)       # active voxels of every segment
-    _lib.check(L.tomo_mc_classify(_p(f.signs), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
+    _lib.check(L.tomo_mc_classify(_p(f.signs), _p(f.gcls), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
     seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     active_segs = torch.empty(nseg, dtype=torch.int32, device=dev)
     totals = torch.zeros(8, dtype=torch.int64, device=dev)

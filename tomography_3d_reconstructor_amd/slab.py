@@ -179,7 +179,8 @@ class HipEngine:
 
     def field_slices(self, f, a, b):
         return pipeline.Field(f.data[a:b], b - a, f.Ny, f.Nx, f.pitch, f.xorg,
-                              f.signs[a:b] if f.signs is not None else None, f.signs_level)
+                              f.signs[a:b] if f.signs is not None else None, f.signs_level,
+                              f.gcls[a:b] if f.gcls is not None else None)
 
     def field_set_slice(self, f, z, slice_data):
         f.data[z].copy_(slice_data.reshape(f.data.shape[1], f.data.shape[2]))

@@ -33,10 +33,11 @@ data = torch.empty((n + 2, n + 2, pitch), dtype=torch.float32, device=dev)
 spr = L.tomo_mc_segments_per_row(n + 2, L.tomo_field_xorg(pad))
 nseg = (n + 2) * (n + 2) * spr
 signs = torch.zeros(L.tomo_sign_buffer_words(n + 2, n + 2, n + 2, L.tomo_field_xorg(pad)), dtype=torch.int64, device=dev)
+gcls = torch.empty(((n + 2) * L.tomo_sign_rows(n + 2) // 16 * spr,), dtype=torch.uint8, device=dev)
 seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)
 seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)
 for _ in range(reps):
-    L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), n, n, n, pad, 1, signs.data_ptr(), st)
-    L.tomo_mc_classify(signs.data_ptr(), n + 2, n + 2, n + 2, L.tomo_field_xorg(pad), seg_act.data_ptr(), seg_cnt.data_ptr(), st)
+    L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), n, n, n, pad, 1, signs.data_ptr(), gcls.data_ptr(), st)
+    L.tomo_mc_classify(signs.data_ptr(), gcls.data_ptr(), n + 2, n + 2, n + 2, L.tomo_field_xorg(pad), seg_act.data_ptr(), seg_cnt.data_ptr(), st)
 torch.cuda.synchronize()
 print("done", case, n)

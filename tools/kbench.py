@@ -49,14 +49,15 @@ def main():
         data = torch.empty((nz + 2, ny + 2, pitch), dtype=torch.float32, device=dev)
         t_zero = timeit(lambda: data.zero_())
         signs = torch.zeros(L.tomo_sign_buffer_words(nz + 2, ny + 2, nx + 2, L.tomo_field_xorg(pad)), dtype=torch.int64, device=dev)
-        t_field = timeit(lambda: L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), nz, ny, nx, pad, 1, signs.data_ptr(), st))
+        gcls = torch.empty(((nz + 2) * L.tomo_sign_rows(ny + 2) // 16 * L.tomo_mc_segments_per_row(nx + 2, L.tomo_field_xorg(pad)),), dtype=torch.uint8, device=dev)
+        t_field = timeit(lambda: L.tomo_field_fill(ext.data_ptr(), data.data_ptr(), nz, ny, nx, pad, 1, signs.data_ptr(), gcls.data_ptr(), st))
         t_fin = 0.0
-        f = pipeline.Field(data, nz + 2, ny + 2, nx + 2, pitch, L.tomo_field_xorg(pad), signs[: (nz + 2) * L.tomo_mc_segments_per_row(nx + 2, L.tomo_field_xorg(pad)) * L.tomo_sign_rows(ny + 2) * 4].view(nz + 2, -1, L.tomo_sign_rows(ny + 2), 4), 0.5)
+        f = pipeline.Field(data, nz + 2, ny + 2, nx + 2, pitch, L.tomo_field_xorg(pad), signs[: (nz + 2) * L.tomo_mc_segments_per_row(nx + 2, L.tomo_field_xorg(pad)) * L.tomo_sign_rows(ny + 2) * 4].view(nz + 2, -1, L.tomo_sign_rows(ny + 2), 4), 0.5, gcls.view(nz + 2, L.tomo_sign_rows(ny + 2) // 16, -1))
         spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
         nseg = f.Nz * f.Ny * spr
         seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)
         seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)
-        t_cls = timeit(lambda: L.tomo_mc_classify(signs.data_ptr(), f.Nz, f.Ny, f.Nx, f.xorg, seg_act.data_ptr(), seg_cnt.data_ptr(), st))
+        t_cls = timeit(lambda: L.tomo_mc_classify(signs.data_ptr(), gcls.data_ptr(), f.Nz, f.Ny, f.Nx, f.xorg, seg_act.data_ptr(), seg_cnt.data_ptr(), st))
         t_morph = timeit(lambda: pipeline.smooth(vol, 3, True))
         t_close = timeit(lambda: pipeline.close_ends(vol))
         if name != "noise50" or n <= 256:
