@@ -36,13 +36,13 @@ def test_abi_version_and_error_strings():
 def test_geometry_helpers():
     L = _lib.lib()
     assert L.tomo_words_per_row(1024) == 16 and L.tomo_words_per_row(1025) == 17 and L.tomo_words_per_row(1) == 1
-    assert L.tomo_field_xorg(1) == 31 and L.tomo_field_xorg(0) == 32
+    assert L.tomo_field_xorg(1) == 0 and L.tomo_field_xorg(0) == 0
     for nx in (1, 7, 64, 150, 1024, 2048):
         for pad in (0, 1):
             pitch = L.tomo_field_pitch(nx, pad)
             assert pitch % 32 == 0 and pitch >= L.tomo_field_xorg(pad) + nx + 2 * pad
             assert L.tomo_ext_words_per_row(nx, pad) * 64 >= nx + pad + 6 + 4
-    assert L.tomo_mc_segments_per_row(1026, 31) == 6 and L.tomo_mc_segments_per_row(32, 0) == 1
+    assert L.tomo_mc_segments_per_row(1026, 0) == 5 and L.tomo_mc_segments_per_row(32, 0) == 1
 
 
 def test_argument_checks_do_not_need_a_gpu():

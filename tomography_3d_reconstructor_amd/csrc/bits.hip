@@ -13,12 +13,12 @@ TOMO_API int64_t tomo_words_per_row(int nx) { return ((int64_t)nx + 63) / 64; }
 TOMO_API int64_t tomo_ext_words_per_row(int nx, int pad) { (void)pad; return ((int64_t)nx + 16 + 63) / 64; }
 TOMO_API int64_t tomo_ext_rows(int ny, int pad) { return (int64_t)ny + 2 * pad + 4; }
 TOMO_API int64_t tomo_ext_slices(int nz, int pad) { return (int64_t)nz + 2 * pad + 4; }
-// Field rows: data column x = 0 sits at float column 32 (a 128-byte line boundary) so that every wave-wide
-// float4 store of the field kernel covers whole 128-byte lines; padded column X is at column xorg + X.
-TOMO_API int tomo_field_xorg(int pad) { return 32 - pad; }
+// Field rows: padded column X is float column xorg + X = X; the pitch is a whole number of 128-byte lines (the field
+// kernel writes whole lines only; a 1026-column row costs 33 lines).
+TOMO_API int tomo_field_xorg(int pad) { (void)pad; return 0; }
 TOMO_API int64_t tomo_field_pitch(int nx, int pad)
 {
-    int64_t cols = (int64_t)(32 - pad) + nx + 2 * pad;
+    int64_t cols = (int64_t)nx + 2 * pad;
     return (cols + 31) / 32 * 32;
 }
 // marching-cubes segments are 256 float COLUMNS of a field row, segment s = columns [256 s - 224, 256 s + 32)
@@ -589,13 +589,14 @@ __global__ __launch_bounds__(256) void extend_kernel(const u64 *__restrict__ bit
         const u64 *row = bits + ((int64_t)z * ny + y) * wx;
         u64 cur = W < wx ? row[W] : 0ull;
         u64 prv = (W >= 1 && W - 1 < wx) ? row[W - 1] : 0ull;
-        res = (cur << 4) | (prv >> 60);          // ext bit e = data x + 4 (source tail bits are zero)
+        const int sh = 4 + pad;                  // ext bit e = padded X + 4 = data x + pad + 4 (source tail bits are zero)
+        res = (cur << sh) | (prv >> (64 - sh));
         // the four reflected columns X = -2, -1, Nx, Nx+1 of the padded array
         const int Nx = nx + 2 * pad;
         const int XS[4] = {-2, -1, Nx, Nx + 1};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int e = XS[k] + 4 - pad;
+            int e = XS[k] + 4;
             if ((e >> 6) != W) continue;
             int x = ext_src_index(XS[k], nx, pad);
             u64 bit = x >= 0 ? (row[x >> 6] >> (x & 63)) & 1ull : 0ull;

@@ -10,7 +10,7 @@
 //
 // Kernel structure (memory-bound: 1 bit in, 4 B out per padded voxel) -- "tile sparse":
 //   * the field row is cut into TILES of 32 float columns (one 128-byte line) x 16 rows; float column c
-//     of a row holds the value of extended bit c - 28 (tomo_extend_bits materialises every border rule, so
+//     of a row holds the value of extended bit c + 4 (tomo_extend_bits materialises every border rule, so
 //     there is not a single boundary branch here: pad columns, reflected columns and the unused columns of
 //     the pitch are ordinary outputs);
 //   * a block owns 4 consecutive slices x 16 rows x (up to 64) tiles.  It stages its 8 x 20 input rows of
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     const int jend = FT_MAXT * bx + FT_MAXT - 7 < p.NT ? FT_MAXT * bx + FT_MAXT - 7 : p.NT;
     const int nt = jend - j0;
     const int joff = (j0 + 7) & 7;                  // byte position of tile j0 in its segment's record words
-    const int WS = nt + 1;                          // staged words per row: ext words j0-1 .. j0+nt-1
+    const int WS = nt + 1;                          // staged words per row: ext words j0 .. j0+nt
     const int Y0 = tr * FT_ROWS, Z0 = zg * FT_ZG, SB = p.SB;
     u32 *const s_bits = s_dyn;
     u32 *const s_ror = s_bits + FT_SLOTS * FT_SROWS * WS, *const s_rand = s_ror + FT_SLOTS * WS;
     unsigned char *const s_sign = (unsigned char *)(s_dyn + (((FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~1));
 
     // ---- stage the block's input bits: flat copy of [slot][row][word] (slot = ext slice Z0 + slot, row = ext
-    //      row Y0 + row, word = ext word j0 - 1 + widx); everything outside the extended volume reads as zero
+    //      row Y0 + row, word = ext word j0 + widx); everything outside the extended volume reads as zero
     {
         const int total = FT_SLOTS * FT_SROWS * WS;
         int i = tid;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
 #pragma unroll
             for (int b = 0; b < FT_BATCH; b++) {
                 const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
-                const int ez = Z0 + slot, ey = Y0 + row, gw = j0 - 1 + wi;
+                const int ez = Z0 + slot, ey = Y0 + row, gw = j0 + wi;
                 const bool ok = (base + b * FT_THREADS + tid) < total && ez < p.EZ && ey < p.EY && gw >= 0 && gw < p.EWX32;
                 v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
                 wi += dw; r += drs;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         s_ror[it] = o; s_rand[it] = a;
     }
     __syncthreads();
-    // ---- tile classes: 0 all zero, 1 all one, 2 mixed, 3 no such slice.  Tile j reads ext bits [32j-30, 32j+6)
+    // ---- tile classes: 0 all zero, 1 all one, 2 mixed, 3 no such slice.  Tile j reads ext bits [32j+2, 32j+38)
     //      = bits 2..31 of staged word jl and bits 0..5 of staged word jl+1 (jl = j - j0), 5 slices, 20 rows.
     for (int it = tid; it < FT_ZG * nt; it += FT_THREADS) {
         const int z = it / nt, jl = it - z * nt;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         const bool act = lane < 60 && ti < nmixed;
         const u32 ent = act ? (u32)s_list[ti] : 0u;
         const int z = (int)(ent >> 8), jl = (int)(ent & 0xffu);
-        // this lane's four columns start at float column 32 (j0+jl) - 4 + 4 l = ext bit 32 (j0+jl-1) + 4 l
+        // this lane's four columns start at float column 32 (j0+jl) - 4 + 4 l = ext bit 32 (j0+jl) + 4 l
         const u32 *bp = s_bits + z * SS + jl + (l >= 8 ? 1 : 0);
         const int sh = (4 * l) & 31;
         const bool st = act && l >= 1 && l <= 8;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void field_raw_kernel(const u64 *__restrict__ 
     int X = (int)(i % Nx);
     int64_t r = i / Nx;
     int Y = (int)(r % Ny), Z = (int)(r / Ny);
-    int e = X + 4 - pad;
+    int e = X + 4;
     u64 w = ext[((int64_t)(Z + 2) * EY + (Y + 2)) * EWX + (e >> 6)];
     field[((int64_t)Z * Ny + Y) * pitch + xorg + X] = (float)((w >> (e & 63)) & 1ull);
 }
