@@ -154,17 +154,18 @@ int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int 
  * not found (must stay 0).  z_offset (0 on one GPU) is added to the slice index of every vertex position before
  * rounding: a Z-slab rank emits positions in global padded coordinates. */
 int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                 const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff, const uint32_t *vox_voff,
-                 const uint32_t *vox_foff, const uint8_t *vox_flags, int z_offset, unsigned long long *vkey, float *vpos,
-                 int32_t *faces, unsigned long long *totals, void *stream);
+                 const unsigned long long *vox_key, int64_t na, const unsigned long long *seg_act,
+                 const uint32_t *seg_aoff, const uint32_t *vox_voff, const uint32_t *vox_foff, const uint8_t *vox_flags,
+                 int z_offset, unsigned long long *vkey, float *vpos, int32_t *faces, unsigned long long *totals,
+                 void *stream);   /* seg_act / seg_aoff: from classify / scan_segments (vertex lookup by ballot rank) */
 
 /* 5. (manifold=False only) skimage's first-touch vertex numbering, which the reference returns unchanged when it
  * skips np.unique (surface_extractor.py:67-68): mode 0 writes created[na] = vertices each cell creates in the
  * serial scan; after an exclusive scan (tomo_mc_scan) mode 1 writes ft_rank[provisional vertex] = its number. */
 int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                        const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
-                        const uint32_t *vox_voff, const uint8_t *vox_flags, int mode, uint32_t *created,
-                        const uint32_t *base, int32_t *ft_rank, unsigned long long *totals, void *stream);
+                        const unsigned long long *vox_key, int64_t na, const unsigned long long *seg_act,
+                        const uint32_t *seg_aoff, const uint32_t *vox_voff, const uint8_t *vox_flags, int mode,
+                        uint32_t *created, const uint32_t *base, int32_t *ft_rank, unsigned long long *totals, void *stream);
 
 /* ---------------------------------------------------------------- mesh finalisation */
 /* surface_extractor.py:57-65 + :82-113 on (V,3) float32 rows in place: -1 shift (if shift),

@@ -57,10 +57,10 @@ SIGNATURES = {
     "tomo_mc_scan": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mc_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "tomo_mc_eval": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p]),
-    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p,
+    "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p,
                             _c_p, _c_p, _c_p, _c_p]),
-    "tomo_mc_first_touch": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i, _c_p, _c_p,
-                                   _c_p, _c_p, _c_p]),
+    "tomo_mc_first_touch": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p,
+                                   _c_p, _c_p, _c_p, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_unique": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

@@ -37,6 +37,7 @@ struct McGrid {
 };
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ static inline u64 make_key(int64_t row, int X, int slot)
 {
@@ -436,10 +437,18 @@ __device__ static inline void load_cell(const float *__restrict__ field, const M
     const float *r01 = field + ((int64_t)c.Z * g.Ny + Y1) * g.pitch + g.xorg;
     const float *r10 = field + ((int64_t)Z1 * g.Ny + c.Y) * g.pitch + g.xorg;
     const float *r11 = field + ((int64_t)Z1 * g.Ny + Y1) * g.pitch + g.xorg;
-    c.v[0] = (double)r00[c.X] - g.iso; c.v[1] = (double)r00[X1] - g.iso;
-    c.v[2] = (double)r01[X1] - g.iso;  c.v[3] = (double)r01[c.X] - g.iso;
-    c.v[4] = (double)r10[c.X] - g.iso; c.v[5] = (double)r10[X1] - g.iso;
-    c.v[6] = (double)r11[X1] - g.iso;  c.v[7] = (double)r11[c.X] - g.iso;
+    float a0, a1, b0, b1, c0, c1, d0, d1;
+    if (X1 != c.X) {       // columns X, X+1 of the four rows: one 8-byte (4-byte aligned) load each
+        const float2u pa = *(const float2u *)(r00 + c.X), pb = *(const float2u *)(r01 + c.X);
+        const float2u pc = *(const float2u *)(r10 + c.X), pd = *(const float2u *)(r11 + c.X);
+        a0 = pa.x; a1 = pa.y; b0 = pb.x; b1 = pb.y; c0 = pc.x; c1 = pc.y; d0 = pd.x; d1 = pd.y;
+    } else {
+        a0 = a1 = r00[c.X]; b0 = b1 = r01[c.X]; c0 = c1 = r10[c.X]; d0 = d1 = r11[c.X];
+    }
+    c.v[0] = (double)a0 - g.iso; c.v[1] = (double)a1 - g.iso;
+    c.v[2] = (double)b1 - g.iso; c.v[3] = (double)b0 - g.iso;
+    c.v[4] = (double)c0 - g.iso; c.v[5] = (double)c1 - g.iso;
+    c.v[6] = (double)d1 - g.iso; c.v[7] = (double)d0 - g.iso;
     int idx = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) idx |= (c.v[i] > 0.0 ? 1 : 0) << i;
@@ -482,27 +491,64 @@ TOMO_API int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pi
     return tomo_status();
 }
 
-// index of the vertex (owner voxel key, slot): search the active list inside the owner's segment
-__device__ static inline u32 find_vertex(u64 okey, int slot, const McGrid &g, const u64 *__restrict__ vox_key,
+// index of the vertex (owner voxel key, slot).  The owner's position in the active-voxel list is its segment's offset
+// plus its rank among the set bits of the segment's four ballots (list order: lanes ascending, k ascending within a lane,
+// see mc_list_kernel) -- two independent loads and a few popcounts instead of a binary search over vox_key.
+__device__ static inline u32 find_vertex(u64 okey, int slot, const McGrid &g, const u64 *__restrict__ seg_act,
                                          const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
                                          const uint8_t *__restrict__ vox_flags)
 {
-    u64 row = okey >> (KEY_XBITS + 2);
-    u32 X = (u32)(okey >> 2) & ((1u << KEY_XBITS) - 1u);
-    u64 seg = row * (u64)g.segs_per_row + ((X + (u32)g.xorg + SEG_SHIFT) >> 8);
-    u32 lo = seg_aoff[seg], end = seg_aoff[seg + 1], hi = end;
-    while (lo < hi) {
-        u32 mid = lo + ((hi - lo) >> 1);
-        if (vox_key[mid] < okey) lo = mid + 1; else hi = mid;
-    }
-    if (lo >= end || vox_key[lo] != okey) return 0xffffffffu;
-    u32 fl = vox_flags[lo];
+    const u64 row = okey >> (KEY_XBITS + 2);
+    const u32 c = ((u32)(okey >> 2) & ((1u << KEY_XBITS) - 1u)) + (u32)g.xorg + SEG_SHIFT;      // float column + shift
+    const u64 seg = row * (u64)g.segs_per_row + (c >> 8);
+    const u32 a0 = seg_aoff[seg], a1 = seg_aoff[seg + 1];
+    if (a1 == a0) return 0xffffffffu;                    // empty segment: its ballot record was never written
+    const Rec4 r = load_rec(seg_act, (int64_t)seg);
+    const int L = (int)((c & 255u) >> 2), k = (int)(c & 3u);
+    const u64 bk = k == 0 ? r.b[0] : (k == 1 ? r.b[1] : (k == 2 ? r.b[2] : r.b[3]));
+    if (!((bk >> L) & 1ull)) return 0xffffffffu;
+    const u64 m = (1ull << L) - 1ull;
+    u32 rank = (u32)(__popcll(r.b[0] & m) + __popcll(r.b[1] & m) + __popcll(r.b[2] & m) + __popcll(r.b[3] & m));
+    rank += (k > 0 ? (u32)((r.b[0] >> L) & 1ull) : 0u) + (k > 1 ? (u32)((r.b[1] >> L) & 1ull) : 0u) +
+            (k > 2 ? (u32)((r.b[2] >> L) & 1ull) : 0u);
+    const u32 pos = a0 + rank;
+    const u32 fl = vox_flags[pos];
     if (!(fl & (1u << slot))) return 0xffffffffu;
-    return vox_voff[lo] + (u32)__popc(fl & ((1u << slot) - 1u));
+    return vox_voff[pos] + (u32)__popc(fl & ((1u << slot) - 1u));
+}
+
+// (vertex base << 4 | flags) of the active voxel `okey`, or 0xffffffff if it is not in the list
+__device__ static inline u32 find_owner(u64 okey, const McGrid &g, const u64 *__restrict__ seg_act,
+                                        const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
+                                        const uint8_t *__restrict__ vox_flags, u32 *flags_out)
+{
+    const u64 row = okey >> (KEY_XBITS + 2);
+    const u32 c = ((u32)(okey >> 2) & ((1u << KEY_XBITS) - 1u)) + (u32)g.xorg + SEG_SHIFT;
+    const u64 seg = row * (u64)g.segs_per_row + (c >> 8);
+    const u32 a0 = seg_aoff[seg], a1 = seg_aoff[seg + 1];
+    if (a1 == a0) return 0xffffffffu;
+    const Rec4 r = load_rec(seg_act, (int64_t)seg);
+    const int L = (int)((c & 255u) >> 2), k = (int)(c & 3u);
+    const u64 bk = k == 0 ? r.b[0] : (k == 1 ? r.b[1] : (k == 2 ? r.b[2] : r.b[3]));
+    if (!((bk >> L) & 1ull)) return 0xffffffffu;
+    const u64 m = (1ull << L) - 1ull;
+    u32 rank = (u32)(__popcll(r.b[0] & m) + __popcll(r.b[1] & m) + __popcll(r.b[2] & m) + __popcll(r.b[3] & m));
+    rank += (k > 0 ? (u32)((r.b[0] >> L) & 1ull) : 0u) + (k > 1 ? (u32)((r.b[1] >> L) & 1ull) : 0u) +
+            (k > 2 ? (u32)((r.b[2] >> L) & 1ull) : 0u);
+    const u32 pos = a0 + rank;
+    *flags_out = vox_flags[pos];
+    return vox_voff[pos];
+}
+
+__device__ static inline u32 slot_vertex(u32 base, u32 flags, int slot)
+{   // index of the vertex in `slot` of a voxel whose first vertex is `base`, 0xffffffff if it has none there
+    if (base == 0xffffffffu || !(flags & (1u << slot))) return 0xffffffffu;
+    return base + (u32)__popc(flags & ((1u << slot) - 1u));
 }
 
 __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ field, const McGrid g,
                                                       const u64 *__restrict__ vox_key, int64_t na,
+                                                      const u64 *__restrict__ seg_act,
                                                       const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_voff,
                                                       const u32 *__restrict__ vox_foff, const uint8_t *__restrict__ vox_flags,
                                                       int z_offset, u64 *__restrict__ vkey, float *__restrict__ vpos,
@@ -547,50 +593,84 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
     McTiling t = mc_cell_tiling(c.v, c.index);
     u32 fo = vox_foff[i];
     const int64_t rowY = (int64_t)g.Ny;
+    // Vertex index of every cube edge that carries one (the edge is bichromatic), ONE list lookup per owner voxel:
+    // edges 1,9 belong to voxel (x+1,y,z), 2,11 to (x,y+1,z), 4,7 to (x,y,z+1), 10 / 5 / 6 to the three diagonal ones.
+    const int ix = c.index;
+#define BICH(a, b) ((((ix >> (a)) ^ (ix >> (b))) & 1) != 0)
+    const bool e1 = BICH(1, 2), e2 = BICH(2, 3), e4 = BICH(4, 5), e5 = BICH(5, 6), e6 = BICH(6, 7), e7 = BICH(7, 4);
+    const bool e9 = BICH(1, 5), e10 = BICH(2, 6), e11 = BICH(3, 7);
+#undef BICH
+    u32 id[13];
+    id[0] = slot_vertex(vox_voff[i], (u32)flags, 0);
+    id[3] = slot_vertex(vox_voff[i], (u32)flags, 1);
+    id[8] = slot_vertex(vox_voff[i], (u32)flags, 2);
+    id[12] = slot_vertex(vox_voff[i], (u32)flags, 3);
+    {   // (x+1, y, z): the next entry of the list if it is active at all (coalesced loads)
+        u32 fl = 0, base = 0xffffffffu;
+        if ((e1 || e9) && i + 1 < na && vox_key[i + 1] == key + 4ull) { base = vox_voff[i + 1]; fl = vox_flags[i + 1]; }
+        id[1] = slot_vertex(base, fl, 1); id[9] = slot_vertex(base, fl, 2);
+    }
+    {
+        u32 fl = 0, base = 0xffffffffu;
+        if (e2 || e11) base = find_owner(make_key(c.row + 1, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
+        id[2] = slot_vertex(base, fl, 0); id[11] = slot_vertex(base, fl, 2);
+    }
+    {
+        u32 fl = 0, base = 0xffffffffu;
+        if (e4 || e7) base = find_owner(make_key(c.row + rowY, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
+        id[4] = slot_vertex(base, fl, 0); id[7] = slot_vertex(base, fl, 1);
+    }
+    {
+        u32 fl = 0, base = 0xffffffffu;
+        if (e10) base = find_owner(make_key(c.row + 1, c.X + 1, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
+        id[10] = slot_vertex(base, fl, 2);
+    }
+    {
+        u32 fl = 0, base = 0xffffffffu;
+        if (e5) base = find_owner(make_key(c.row + rowY, c.X + 1, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
+        id[5] = slot_vertex(base, fl, 1);
+    }
+    {
+        u32 fl = 0, base = 0xffffffffu;
+        if (e6) base = find_owner(make_key(c.row + 1 + rowY, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
+        id[6] = slot_vertex(base, fl, 0);
+    }
     bool bad = false;
     for (int tI = 0; tI < t.ntri; tI++) {
-        int32_t id[3];
+        int32_t tv[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            int ed = t.tris[3 * tI + j];
-            int dx = (ed == 1 || ed == 5 || ed == 9 || ed == 10) ? 1 : 0;
-            int dy = (ed == 2 || ed == 6 || ed == 10 || ed == 11) ? 1 : 0;
-            int dz = (ed >= 4 && ed <= 7) ? 1 : 0;
-            int slot = ed == 12 ? 3 : (ed >= 8 ? 2 : (ed & 1));
-            u32 v;
-            if ((dx | dy | dz) == 0) {           // owned by this voxel: no search
-                v = vox_voff[i] + (u32)__popc(flags & ((1 << slot) - 1));
-                if (!(flags & (1 << slot))) v = 0xffffffffu;
-            } else {
-                v = find_vertex(make_key(c.row + dy + dz * rowY, c.X + dx, 0), slot, g, vox_key, seg_aoff, vox_voff,
-                                vox_flags);
-            }
+            const int ed = t.tris[3 * tI + j];
+            u32 v = id[0];                          // select chain: id[] stays in registers
+#pragma unroll
+            for (int e = 1; e < 13; e++) v = ed == e ? id[e] : v;
             bad |= (v == 0xffffffffu);
-            id[j] = (int32_t)v;
+            tv[j] = (int32_t)v;
         }
         int32_t *fp = faces + 3 * (int64_t)fo;
-        fp[0] = id[2]; fp[1] = id[1]; fp[2] = id[0];   // np.fliplr(faces) of the skimage wrapper
+        fp[0] = tv[2]; fp[1] = tv[1]; fp[2] = tv[0];   // np.fliplr(faces) of the skimage wrapper
         fo++;
     }
     if (bad) atomicAdd(&totals[3], 1ull);
 }
 
 TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                          const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
-                          const uint32_t *vox_voff, const uint32_t *vox_foff, const uint8_t *vox_flags, int z_offset,
-                          unsigned long long *vkey, float *vpos, int32_t *faces, unsigned long long *totals, void *stream)
+                          const unsigned long long *vox_key, int64_t na, const unsigned long long *seg_act,
+                          const uint32_t *seg_aoff, const uint32_t *vox_voff, const uint32_t *vox_foff,
+                          const uint8_t *vox_flags, int z_offset, unsigned long long *vkey, float *vpos, int32_t *faces,
+                          unsigned long long *totals, void *stream)
 {
     McGrid g;
     int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
     if (rc) return rc;
-    if (!vox_key || !seg_aoff || !vox_voff || !vox_foff || !vox_flags || !vkey || !vpos || !faces || !totals)
+    if (!vox_key || !seg_act || !seg_aoff || !vox_voff || !vox_foff || !vox_flags || !vkey || !vpos || !faces || !totals)
         return TOMO_E_ARG;
     if (na <= 0) return TOMO_OK;
     int64_t blocks = ceil_div64(na, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
-                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_foff, vox_flags, z_offset, (u64 *)vkey, vpos, faces,
-                       (u64 *)totals);
+                       (const u64 *)vox_key, na, (const u64 *)seg_act, seg_aoff, vox_voff, vox_foff, vox_flags, z_offset,
+                       (u64 *)vkey, vpos, faces, (u64 *)totals);
     return tomo_status();
 }
 
@@ -603,6 +683,7 @@ TOMO_API int tomo_mc_emit(const float *field, int Nz, int Ny, int Nx, int64_t pi
 // mode 0: created[i] = number of vertices cell i creates;  mode 1: ft_rank[provisional id] = base[i] + j.
 __global__ __launch_bounds__(256) void mc_first_touch_kernel(const float *__restrict__ field, const McGrid g,
                                                              const u64 *__restrict__ vox_key, int64_t na,
+                                                             const u64 *__restrict__ seg_act,
                                                              const u32 *__restrict__ seg_aoff,
                                                              const u32 *__restrict__ vox_voff,
                                                              const uint8_t *__restrict__ vox_flags, int mode,
@@ -637,7 +718,7 @@ __global__ __launch_bounds__(256) void mc_first_touch_kernel(const float *__rest
             if (mode == 1) {
                 u32 v;
                 if ((dx | dy | dz) == 0) v = (flags & (1 << slot)) ? vox_voff[i] + (u32)__popc(flags & ((1 << slot) - 1)) : 0xffffffffu;
-                else v = find_vertex(make_key(c.row + dy + dz * rowY, ox, 0), slot, g, vox_key, seg_aoff, vox_voff, vox_flags);
+                else v = find_vertex(make_key(c.row + dy + dz * rowY, ox, 0), slot, g, seg_act, seg_aoff, vox_voff, vox_flags);
                 if (v == 0xffffffffu) atomicAdd(&totals[3], 1ull);
                 else ft_rank[v] = (int32_t)(base[i] + n);
             }
@@ -648,20 +729,22 @@ __global__ __launch_bounds__(256) void mc_first_touch_kernel(const float *__rest
 }
 
 TOMO_API int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
-                                 const unsigned long long *vox_key, int64_t na, const uint32_t *seg_aoff,
-                                 const uint32_t *vox_voff, const uint8_t *vox_flags, int mode, uint32_t *created,
+                                 const unsigned long long *vox_key, int64_t na, const unsigned long long *seg_act,
+                                 const uint32_t *seg_aoff, const uint32_t *vox_voff, const uint8_t *vox_flags, int mode,
+                                 uint32_t *created,
                                  const uint32_t *base, int32_t *ft_rank, unsigned long long *totals, void *stream)
 {
     McGrid g;
     int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
     if (rc) return rc;
-    if (!vox_key || !seg_aoff || !vox_voff || !vox_flags || !totals || (mode == 0 && !created) ||
+    if (!vox_key || !seg_act || !seg_aoff || !vox_voff || !vox_flags || !totals || (mode == 0 && !created) ||
         (mode == 1 && (!base || !ft_rank)) || (mode != 0 && mode != 1))
         return TOMO_E_ARG;
     if (na <= 0) return TOMO_OK;
     int64_t blocks = ceil_div64(na, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_first_touch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
-                       (const u64 *)vox_key, na, seg_aoff, vox_voff, vox_flags, mode, created, base, ft_rank, (u64 *)totals);
+                       (const u64 *)vox_key, na, (const u64 *)seg_act, seg_aoff, vox_voff, vox_flags, mode, created, base, ft_rank,
+                       (u64 *)totals);
     return tomo_status();
 }

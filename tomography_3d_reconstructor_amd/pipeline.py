@@ -252,7 +252,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     vox_key = torch.empty(na, dtype=torch.int64, device=dev)
     _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(active_segs), nas, _p(vox_key), st),
                "tomo_mc_list")
-    del active_segs, seg_act, seg_cnt
+    del active_segs, seg_cnt
     vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
     vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
     _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")
@@ -272,10 +272,10 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     vkey = torch.empty(nv, dtype=torch.int64, device=dev)
     vpos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
     faces32 = torch.empty((max(nf, 1), 3), dtype=torch.int32, device=dev)
-    _lib.check(L.tomo_mc_emit(_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_foff), _p(vox_flags),
+    _lib.check(L.tomo_mc_emit(_p(f.data), *geo, _p(vox_key), na, _p(seg_act), _p(seg_aoff), _p(vox_voff), _p(vox_foff), _p(vox_flags),
                               int(z_offset), _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
     mesh = RawMesh(vkey, vpos, faces32[:nf])
-    mesh._mc = (f, geo, vox_key, na, seg_aoff, vox_voff, vox_flags)   # for first_touch_order (manifold=False)
+    mesh._mc = (f, geo, vox_key, na, seg_act, seg_aoff, vox_voff, vox_flags)   # for first_touch_order (manifold=False)
     mesh._err = tot2   # tot2[3] != 0 would mean a triangle corner without vertex (checked after the next sync)
     return mesh
 
@@ -334,13 +334,13 @@ def first_touch_order(mesh: RawMesh):
     """Renumber a RawMesh the way skimage numbers vertices (order of first touch in the serial cell scan).
     Returns (vpos (V,3) float32, faces (F,3) int32): what measure.marching_cubes returns to the reference."""
     L = _lib.lib()
-    f, geo, vox_key, na, seg_aoff, vox_voff, vox_flags = mesh._mc
+    f, geo, vox_key, na, seg_act, seg_aoff, vox_voff, vox_flags = mesh._mc
     dev = mesh.vpos.device
     st = _stream()
     nv = mesh.vpos.shape[0]
     created = torch.empty(na, dtype=torch.int32, device=dev)
     totals = torch.zeros(4, dtype=torch.int64, device=dev)
-    args = (_p(f.data), *geo, _p(vox_key), na, _p(seg_aoff), _p(vox_voff), _p(vox_flags))
+    args = (_p(f.data), *geo, _p(vox_key), na, _p(seg_act), _p(seg_aoff), _p(vox_voff), _p(vox_flags))
     _lib.check(L.tomo_mc_first_touch(*args, 0, _p(created), None, None, _p(totals), st), "tomo_mc_first_touch")
     base = torch.empty(na + 1, dtype=torch.int32, device=dev)
     wsb = L.tomo_mc_scan_workspace_bytes(na)
