@@ -71,8 +71,22 @@ __global__ __launch_bounds__(256) void uq_gather_kernel(const float *__restrict_
     kzy[i] = ((u64)fkey32(p[0]) << 32) | (u64)fkey32(p[1]);
 }
 
+// (z, y) keys of the rows in their given order (the one-sort path)
+__global__ __launch_bounds__(256) void uq_keys_zy_kernel(const float *__restrict__ vpos, int64_t nv, u64 *__restrict__ kzy,
+                                                         u32 *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const float *p = vpos + 3 * i;
+    kzy[i] = ((u64)fkey32(p[0]) << 32) | (u64)fkey32(p[1]);
+    idx[i] = (u32)i;
+}
+
+// head[i] = row idx[i] differs from row idx[i-1]; with `violations` also counts the places where two consecutive
+// rows have equal (z, y) but DEscending x (the one-sort path is only valid when there are none)
 __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__ vpos, int64_t nv,
-                                                       const u32 *__restrict__ idx, u32 *__restrict__ head)
+                                                       const u32 *__restrict__ idx, u32 *__restrict__ head,
+                                                       u64 *__restrict__ violations)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
@@ -80,6 +94,7 @@ __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__
     if (i > 0) {
         const float *a = vpos + 3 * (int64_t)idx[i], *b = vpos + 3 * (int64_t)idx[i - 1];
         h = (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
+        if (violations && a[0] == b[0] && a[1] == b[1] && a[2] < b[2]) atomicAdd(violations, 1ull);
     }
     head[i] = h;
 }
@@ -153,7 +168,38 @@ TOMO_API int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_
     hipLaunchKernelGGL(uq_gather_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_b, kzy_a);
     tb = L.temp_bytes;
     if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 64, s) != hipSuccess) return TOMO_E_LAUNCH;
-    hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head);
+    hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head, (u64 *)nullptr);
+    tb = L.temp_bytes;
+    if (rocprim::inclusive_scan(temp, tb, head, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_scatter_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)head,
+                       (const u32 *)hscan, uniq, rank, (u64 *)totals);
+    return tomo_status();
+}
+
+// One-sort variant for rows that arrive in marching-cubes order (owner voxel z, y, x, then slot): rows with equal
+// (z, y) are then almost always already ascending in x -- x-edge vertices of a row ascend with the owner's x, and so do
+// y- / z-edge vertices that share their fractional coordinate -- so ONE stable sort on (z, y) yields the lexicographic
+// order and the 32-bit x sort is skipped.  "Almost": a float32 rounding coincidence can put a later row before an
+// earlier one; every such place is counted in totals[2] and the caller must then redo the call with tomo_mesh_unique
+// (the result is exact if and only if totals[2] == 0).  Same workspace size.
+TOMO_API int tomo_mesh_unique_presorted(const float *vpos, int64_t nv, float *uniq, int32_t *rank,
+                                        unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!vpos || !uniq || !rank || !totals || !workspace || nv <= 0) return TOMO_E_ARG;
+    if (nv >= 0x7fffffffll) return TOMO_E_SIZE;
+    UqLayout L = uq_layout(nv);
+    if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    u32 *idx_b = (u32 *)(ws + L.idx_b), *idx_c = (u32 *)(ws + L.idx_c);
+    u64 *kzy_a = (u64 *)(ws + L.kzy_a), *kzy_b = (u64 *)(ws + L.kzy_b);
+    u32 *head = (u32 *)(ws + L.head), *hscan = (u32 *)(ws + L.hscan);
+    void *temp = ws + L.temp;
+    size_t tb = L.temp_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned blocks = (unsigned)ceil_div64(nv, 256);
+    hipLaunchKernelGGL(uq_keys_zy_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, kzy_a, idx_b);
+    if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 64, s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head, (u64 *)totals + 2);
     tb = L.temp_bytes;
     if (rocprim::inclusive_scan(temp, tb, head, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
     hipLaunchKernelGGL(uq_scatter_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)head,

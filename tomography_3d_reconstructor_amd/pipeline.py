@@ -299,30 +299,35 @@ def finalize_vertices(vpos: torch.Tensor, slice_depths, mm_per_pixel_y, mm_per_p
     return vpos
 
 
-def ensure_manifold_mesh(mesh: RawMesh):
+def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     """_ensure_manifold_mesh (surface_extractor.py:115-126): unique vertex rows (lexicographic order) and
-    remapped int64 faces without degenerate triangles.  mesh.vpos must already be finalised."""
+    remapped int64 faces without degenerate triangles.  mesh.vpos must already be finalised.
+    presorted: the rows are in marching-cubes order, so try the one-sort path first (tomo_mesh_unique_presorted)
+    and fall back to the two-sort path if it reports an order violation."""
     L = _lib.lib()
     dev = mesh.vpos.device
     nv, nf = mesh.vpos.shape[0], mesh.faces32.shape[0]
-    totals = torch.zeros(4, dtype=torch.int64, device=dev)
     uniq = torch.empty((nv, 3), dtype=torch.float32, device=dev)
     rank = torch.empty(nv, dtype=torch.int32, device=dev)
     wsb = L.tomo_mesh_unique_workspace_bytes(nv)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mesh_unique(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
-               "tomo_mesh_unique")
-    faces = None
+    faces = torch.empty((nf, 3), dtype=torch.int64, device=dev) if nf > 0 else None
+    ws2 = None
     if nf > 0:
-        faces = torch.empty((nf, 3), dtype=torch.int64, device=dev)
         wsb2 = L.tomo_mesh_faces_workspace_bytes(nf)
         ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
-        _lib.check(L.tomo_mesh_faces(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _p(ws2), wsb2, _stream()),
-                   "tomo_mesh_faces")
     err = getattr(mesh, "_err", None)
-    if err is not None:
-        totals[3] = err[3]
-    nu, nkeep, _, nbad = [int(x) for x in totals.cpu()]
+    for fn in ((L.tomo_mesh_unique_presorted, L.tomo_mesh_unique) if presorted else (L.tomo_mesh_unique,)):
+        totals = torch.zeros(4, dtype=torch.int64, device=dev)
+        _lib.check(fn(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_unique")
+        if nf > 0:
+            _lib.check(L.tomo_mesh_faces(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _p(ws2), wsb2, _stream()),
+                       "tomo_mesh_faces")
+        if err is not None:
+            totals[3] = err[3]
+        nu, nkeep, nviol, nbad = [int(x) for x in totals.cpu()]
+        if nviol == 0:
+            break
     if nbad:
         raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % nbad)
     verts = uniq[:nu]
