@@ -89,6 +89,21 @@ def test_binary_stages_vs_oracle(dev, shape, p):
     assert np.array_equal(to_np(pipeline.smooth(vol, 2, True)), O.smooth(v, 2, True))
 
 
+@pytest.mark.parametrize("shape", [(20, 130, 257), (9, 70, 262), (37, 57, 320), (12, 120, 513), (70, 9, 64), (5, 200, 1025),
+                                   (11, 64, 255), (3, 1, 700), (1, 90, 129)])
+@pytest.mark.parametrize("it,cm", [(3, True), (1, True), (2, False), (3, False), (0, True)])
+def test_smooth_tile_edges_vs_oracle(dev, shape, it, cm):
+    """The one-wave-per-tile smoothing kernel: rows wider than a 4-word strip with the tail in every position relative
+    to the strip and its 8-bit halo, several 56-row tiles, slices across z chunks, 2 / 4 / 6 / 8 passes."""
+    rng = np.random.default_rng(shape[2] + it)
+    v = rng.random(shape) < 0.82
+    v[:, : shape[1] // 3, -(shape[2] // 5 + 1):] = True          # solid block against the right border and the tail word
+    v[shape[0] // 2:, shape[1] // 2:, : shape[2] // 7 + 1] = rng.random((shape[0] - shape[0] // 2, shape[1] - shape[1] // 2,
+                                                                       shape[2] // 7 + 1)) < 0.5
+    got = to_np(pipeline.smooth(to_vol(v, dev), it, cm))
+    assert np.array_equal(got, O.smooth(v, it, cm))
+
+
 def test_fill_holes_spiral(dev):
     # a long corridor: the flood has to travel far (many iterations of the device loop)
     n = 96

@@ -525,12 +525,155 @@ __global__ __launch_bounds__(1024) void morph_fused_kernel(const u64 *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Barrier-free variant for H <= 4 passes: ONE WAVE owns a whole (x, y) tile cross-section, so no stage needs LDS or a
+// barrier.  Lane = row (64 rows, 64 - 2H owned), registers = a strip of FW_W owned words of that row plus ONE "halo
+// word" whose top 8 bits are the 8 voxels left of the strip and whose low 8 bits the 8 voxels right of it.  The five
+// words form a ring (halo word between the last and the first owned word), which makes every word's x-neighbours the
+// previous / next word of the ring -- uniform code, no edge cases; the unused middle bits of the halo word decay by one
+// bit per pass, exactly like the outer rows of the tile.  y-neighbours are the adjacent lanes (DPP wave shifts),
+// z-neighbours the previous values in registers (same software pipeline along z as above).
+// The block version spends its time in barriers (8 per slice, 16 waves each); this one is pure VALU.
+#define FW_W 4
+
+__device__ static inline u64 dpp_prev_u64(u64 v)
+{   // value of lane - 1 (lane 0: 0, by bound_ctrl -- no "old" operand to initialise)
+    return ((u64)(u32)__builtin_amdgcn_mov_dpp((int)(u32)(v >> 32), 0x138 /* wave_shr:1 */, 0xf, 0xf, true) << 32) |
+           (u64)(u32)__builtin_amdgcn_mov_dpp((int)(u32)v, 0x138, 0xf, 0xf, true);
+}
+__device__ static inline u64 dpp_next_u64(u64 v)
+{   // value of lane + 1 (lane 63: 0)
+    return ((u64)(u32)__builtin_amdgcn_mov_dpp((int)(u32)(v >> 32), 0x130 /* wave_shl:1 */, 0xf, 0xf, true) << 32) |
+           (u64)(u32)__builtin_amdgcn_mov_dpp((int)(u32)v, 0x130, 0xf, 0xf, true);
+}
+
+// OPS >= 0: the pass mask is a compile-time constant (the masks smooth_voxel_data produces), which removes every
+// per-pass select; OPS < 0: generic, mask in `ops`.
+template <int H, int OPS>
+__global__ __launch_bounds__(256) void morph_wave_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int nz, int ny,
+                                                         int nx, int wx, u32 ops, int zchunk, int nxt, int nyt, int64_t nwaves)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const int xt = (int)(wid % nxt), yt = (int)((wid / nxt) % nyt), zc = (int)(wid / ((int64_t)nxt * nyt));
+    const int w0 = xt * FW_W;
+    const int rows_own = 64 - 2 * H;
+    const int y0 = yt * rows_own, y = y0 - H + lane;
+    const int za = zc * zchunk, zb = za + zchunk < nz ? za + zchunk : nz;
+    const bool rowv = y >= 0 && y < ny;
+    const bool own_row = rowv && lane >= H && lane < 64 - H;
+    const u64 outside = rowv ? 0ull : ~0ull;              // rows outside the volume read as the pass's border value
+    const u64 tailmask = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
+    // the right half of the halo word are the low bits of word w0 + FW_W: if that is the row's last word its bits beyond
+    // nx are outside the volume too
+    const u64 hmask = (w0 + FW_W == wx - 1) ? (tailmask | ~0xffull) : ~0ull;
+    const int64_t sw = (int64_t)ny * wx;
+    const int64_t rowoff = rowv ? (int64_t)y * wx : 0;
+    // ring positions 0..FW_W-1 = owned words w0+k, position FW_W = halo word
+    u64 P[H][FW_W + 1], L1[H][FW_W + 1], L2[H][FW_W + 1];
+#pragma unroll
+    for (int j = 0; j < H; j++)
+#pragma unroll
+        for (int k = 0; k <= FW_W; k++) { P[j][k] = 0; L1[j][k] = 0; L2[j][k] = 0; }
+    // level-0 words of slice t: FW_W owned words + the two neighbours the halo word is cut from (loaded one slice ahead)
+    u64 N[FW_W + 2];
+#define FW_LOAD(tt)                                                                              \
+    {                                                                                            \
+        const bool sv = rowv && (tt) >= 0 && (tt) < nz;                                          \
+        const u64 *src = in + (int64_t)(tt) * sw + rowoff;                                       \
+        _Pragma("unroll") for (int k = 0; k < FW_W; k++) N[k] = (sv && w0 + k < wx) ? src[w0 + k] : 0ull; \
+        N[FW_W] = (sv && w0 - 1 >= 0) ? src[w0 - 1] : 0ull;                                      \
+        N[FW_W + 1] = (sv && w0 + FW_W < wx) ? src[w0 + FW_W] : 0ull;                            \
+    }
+    FW_LOAD(za - H);
+    for (int t = za - H; t < zb + H; t++) {
+        u64 X[FW_W + 1];
+#pragma unroll
+        for (int k = 0; k < FW_W; k++) X[k] = N[k];
+        X[FW_W] = (N[FW_W] & 0xff00000000000000ull) | (N[FW_W + 1] & 0xffull);
+        if (t + 1 < zb + H) FW_LOAD(t + 1);               // in flight while this slice is computed
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const int op = OPS >= 0 ? ((OPS >> j) & 1) : (int)((ops >> j) & 1u);     // 0 erosion (border 1), 1 dilation (border 0)
+            const int sX = t - j;
+            const u64 zout = (sX >= 0 && sX < nz) ? 0ull : ~0ull;                   // wave-uniform
+            u64 C[FW_W + 1];
+#pragma unroll
+            for (int k = 0; k <= FW_W; k++) {
+                // level j of slice sX as the passes see it: the border value outside the volume (z, then y and the tail)
+                const u64 Xe = op == 0 ? (X[k] | zout) : (X[k] & ~zout);
+                const u64 o = op == 0 ? (P[j][k] & L2[j][k] & Xe) : (P[j][k] | L2[j][k] | Xe);
+                L2[j][k] = L1[j][k];
+                L1[j][k] = Xe;
+                u64 c = op == 0 ? (X[k] | outside) : (X[k] & ~outside);
+                if (op == 0) {
+                    if (k < FW_W && w0 + k == wx - 1) c |= ~tailmask;
+                    if (k == FW_W) c |= ~hmask;
+                }
+                C[k] = c;
+                X[k] = o;                                 // level j + 1 of slice sX - 1 (masked below)
+            }
+#pragma unroll
+            for (int k = 0; k <= FW_W; k++) {
+                const int kp = k == 0 ? FW_W : k - 1, kn = k == FW_W ? 0 : k + 1;
+                u32 lin = (u32)(C[kp] >> 32), rin = (u32)C[kn];                     // words whose bit 63 / bit 0 shift in
+                if (k < FW_W) {                                                       // volume border in x
+                    if (w0 + k <= 0) lin = op == 0 ? ~0u : 0u;
+                    if (w0 + k >= wx - 1) rin = op == 0 ? ~0u : 0u;
+                }
+                const u32 clo = (u32)C[k], chi = (u32)(C[k] >> 32);
+                const u64 xl = ((u64)__builtin_amdgcn_alignbit(chi, clo, 31) << 32) | __builtin_amdgcn_alignbit(clo, lin, 31);
+                const u64 xh = ((u64)__builtin_amdgcn_alignbit(rin, chi, 1) << 32) | __builtin_amdgcn_alignbit(chi, clo, 1);
+                const u64 yl = dpp_prev_u64(C[k]), yh = dpp_next_u64(C[k]);
+                P[j][k] = op == 0 ? (C[k] & yl & yh & xl & xh) : (C[k] | yl | yh | xl | xh);
+            }
+            if (w0 + FW_W - 1 >= wx - 1) {                                            // wave-uniform: the strip holds the last word
+#pragma unroll
+                for (int k = 0; k < FW_W; k++) if (w0 + k == wx - 1) X[k] &= tailmask;
+            }
+            X[FW_W] &= hmask;
+        }
+        const int so = t - H;
+        if (own_row && so >= za && so < zb) {
+            u64 *dst = out + (int64_t)so * sw + rowoff;
+#pragma unroll
+            for (int k = 0; k < FW_W; k++) if (w0 + k < wx) dst[w0 + k] = X[k];
+        }
+    }
+}
+#undef FW_LOAD
+
+template <int H>
+static int morph_wave_launch(const u64 *in, u64 *out, int nz, int ny, int nx, int wx, u32 ops, hipStream_t s)
+{
+    const int rows_own = 64 - 2 * H;
+    const int nxt = (wx + FW_W - 1) / FW_W, nyt = (ny + rows_own - 1) / rows_own;
+    int zchunk = nz;
+    while (zchunk > 16 && (int64_t)nxt * nyt * ceil_div64(nz, zchunk) < 2048) zchunk = (zchunk + 1) / 2;   // two waves per SIMD
+    const int64_t nwaves = (int64_t)nxt * nyt * ceil_div64(nz, zchunk);
+    const int64_t blocks = ceil_div64(nwaves, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+#define FW_GO(OPSC) hipLaunchKernelGGL((morph_wave_kernel<H, OPSC>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, nz, ny, nx, \
+                                       wx, ops, zchunk, nxt, nyt, nwaves)
+    // the pass masks of smooth_voxel_data: E D D E (opening + first closing), D E D E (two closings), D E, E D
+    if (H == 4 && ops == 6u) FW_GO(6);
+    else if (H == 4 && ops == 5u) FW_GO(5);
+    else if (H == 2 && ops == 1u) FW_GO(1);
+    else if (H == 2 && ops == 2u) FW_GO(2);
+    else FW_GO(-1);
+#undef FW_GO
+    return tomo_status();
+}
+
 TOMO_API int tomo_morph_fused(const uint64_t *in, uint64_t *out, int nz, int ny, int nx, uint32_t ops, int nops,
                               void *stream)
 {
     if (!in || !out || in == out || nz <= 0 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
     if (nops != 2 && nops != 4 && nops != 6 && nops != 8) return TOMO_E_ARG;
     int wx = (int)tomo_words_per_row(nx);
+    if (nops == 2) return morph_wave_launch<2>((const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, (hipStream_t)stream);
+    if (nops == 4) return morph_wave_launch<4>((const u64 *)in, (u64 *)out, nz, ny, nx, wx, ops, (hipStream_t)stream);
     int xh = wx > FM_TW ? 1 : 0;
     int TWH = (wx > FM_TW ? FM_TW : wx) + 2 * xh;
     int TYH = 1024 / TWH;

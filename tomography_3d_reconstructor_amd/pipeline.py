@@ -153,7 +153,7 @@ def smooth(vol: BitVolume, iterations: int = 3, create_manifold: bool = True) ->
     cur = a
     i = 0
     while i < len(ops):
-        n = min(8, len(ops) - i)                   # up to 8 passes per fused launch (n is even: passes come in pairs)
+        n = min(4, len(ops) - i)                   # 4 passes per launch: the barrier-free one-wave-per-tile kernel (n is even)
         mask = sum(op << j for j, op in enumerate(ops[i:i + n]))
         dst = bufs[k]
         k ^= 1
