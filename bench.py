@@ -45,7 +45,7 @@ def parse():
 
 
 class FieldTimer:
-    """HIP events around every tomo_field_fill launch (torch events on the launch stream)."""
+    """HIP events around every field-kernel launch (tomo_field_fill / tomo_field_fill_bits; torch events on the launch stream)."""
 
     def __init__(self):
         self.pairs = []
@@ -55,24 +55,26 @@ class FieldTimer:
 
     def install(self):
         L = _lib.lib()
-        self._orig = L.tomo_field_fill
         timer = self
 
-        def wrapped(*a):
-            if not timer.enabled:
-                return timer._orig(*a)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rc = timer._orig(*a)
-            e1.record()
-            timer.pairs.append((e0, e1))
-            nz, ny, nx, pad = a[2], a[3], a[4], a[5]
-            timer.padded_voxels = (nz + 2 * pad) * (ny + 2 * pad) * (nx + 2 * pad)
-            return rc
+        def wrap(orig):
+            def wrapped(*a):
+                if not timer.enabled:
+                    return orig(*a)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(*a)
+                e1.record()
+                timer.pairs.append((e0, e1))
+                nz, ny, nx, pad = a[2], a[3], a[4], a[5]
+                timer.padded_voxels = (nz + 2 * pad) * (ny + 2 * pad) * (nx + 2 * pad)
+                return rc
+            return wrapped
 
-        # ctypes function objects are attributes of the CDLL instance
-        L.tomo_field_fill = wrapped
+        # ctypes function objects are attributes of the CDLL instance; both entry points launch the field kernel
+        L.tomo_field_fill = wrap(L.tomo_field_fill)
+        L.tomo_field_fill_bits = wrap(L.tomo_field_fill_bits)
 
     def mean_ms(self):
         if not self.pairs:

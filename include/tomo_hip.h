@@ -100,6 +100,10 @@ int tomo_extend_bits(const uint64_t *bits, uint64_t *ext, int nz, int ny, int nx
  * cast to float32.  gaussian = 0 writes the raw 0/1 field (manifold=False). */
 int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, int pad, int gaussian,
                     unsigned long long *signs, uint8_t *gcls, void *stream);   /* `field` must be 128-byte aligned */
+/* The Gaussian field straight from the plain bit volume (no tomo_extend_bits): the block forms the extended words
+ * while it stages its input.  Same outputs as tomo_field_fill(gaussian = 1) on tomo_extend_bits(bits). */
+int tomo_field_fill_bits(const uint64_t *bits, float *field, int nz, int ny, int nx, int pad, unsigned long long *signs,
+                         uint8_t *gcls, void *stream);
 /* Sign records (input of marching-cubes pass 1): uint64 [Nz][S][NyP][4], S = tomo_mc_segments_per_row(Nx, xorg),
  * NyP = tomo_sign_rows(Ny) (Ny rounded up to 16 so that 16-row groups of records are 512-byte aligned);
  * bit L of word k of record (Z, s, Y) = [field(Z, Y, column 256 s - 224 + 4 L + k) > iso].  tomo_field_fill writes

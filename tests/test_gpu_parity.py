@@ -456,3 +456,25 @@ def test_unique_one_sort_path_detects_disorder_and_falls_back(dev):
         gv, gf = pipeline.ensure_manifold_mesh(mesh)
         ev, ef = O.ensure_manifold_mesh(v, f)
         assert np.array_equal(gv.cpu().numpy(), ev) and np.array_equal(gf.cpu().numpy(), ef)
+
+
+@pytest.mark.parametrize("shape,pad", [((5, 7, 9), 1), ((5, 7, 9), 0), ((9, 33, 64), 1), ((4, 20, 1), 0), ((3, 3, 27), 1),
+                                       ((6, 40, 59), 0), ((7, 18, 130), 1), ((3, 5, 2050), 0), ((2, 2, 2), 1), ((1, 1, 1), 0)])
+def test_field_from_bits_equals_field_from_extended_volume(dev, shape, pad, monkeypatch):
+    """tomo_field_fill_bits (border rules applied while staging) == tomo_extend_bits + tomo_field_fill, bit for bit,
+    including the sign records and group classes -- and both equal the oracle."""
+    rng = np.random.default_rng(shape[2] * 7 + pad)
+    v = rng.random(shape) < 0.55
+    vol = to_vol(v, dev)
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(pipeline, "FIELD_FROM_BITS", flag)
+        f = pipeline.make_field(vol, True, bool(pad))
+        res.append((f.dense().cpu().numpy().copy(), f.gcls.cpu().numpy().copy(), f))
+    assert res[0][0].tobytes() == res[1][0].tobytes() == O.field(v, True, bool(pad)).tobytes()
+    assert np.array_equal(res[0][1], res[1][1])
+    stored = torch.from_numpy(res[0][1] == 2).to(dev)             # groups whose records exist: (Nz, G, S)
+    a, b = res[0][2].signs, res[1][2].signs                         # (Nz, S, NyP, 4)
+    m = stored.permute(0, 2, 1).repeat_interleave(16, dim=2)[:, :, :, None]
+    Ny = res[0][2].Ny
+    assert torch.equal((a * m)[:, :, :Ny], (b * m)[:, :, :Ny])

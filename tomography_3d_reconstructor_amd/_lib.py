@@ -47,6 +47,7 @@ SIGNATURES = {
     "tomo_morph_fused": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, ctypes.c_uint32, _c_i, _c_p]),
     "tomo_extend_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_field_fill": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
+    "tomo_field_fill_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
     "tomo_sign_rows": (_c_i64, [_c_i]),
     "tomo_field_signs_fused": (_c_i, [_c_i]),
     "tomo_sign_buffer_words": (_c_i64, [_c_i, _c_i, _c_i, _c_i]),

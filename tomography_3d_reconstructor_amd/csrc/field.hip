@@ -48,6 +48,7 @@ struct FieldParams {
     int EZ, EY, EWX32;              // extended bit volume: slices, rows, 32-bit words per row
     int64_t pitch;
     int nxc, ntr, nzg;              // blocks per row, tile rows, slice groups
+    int nz, ny, nx, pad, SW32;      // (FROM_BITS) the plain bit volume the input is derived from: dims, 32-bit words per row
     u64 *signs;                     // sign records [Nz][S][NyP][4] (may be null)
     unsigned char *gcls;            // class of every group of 16 rows of records [Nz][NyP / 16][S]: 0 / 1 = all bits 0 / 1
                                     // (records not written), 2 = records written
@@ -67,6 +68,61 @@ __device__ static inline double tap5(double a, double b, double c, double d, dou
 //              (8-byte aligned) u8 s_sign[FT_ZG][FT_ROWS][4][SB]
 extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 
+// One 32-bit word of the EXTENDED bit volume (slice ez, row ey, word gw) from the plain bit volume -- what extend_kernel
+// (bits.hip) would have stored there: reflect of the padded array along z and y, a funnel shift by 4 + pad bits along x,
+// and the four reflected columns X = -2, -1, Nx, Nx+1.  Split in two so that the staging loop can issue ALL its loads
+// before it touches any of them: ext_src_addr gives the (always valid) offset of source word gw-1 / gw and the validity
+// bits, ext_word_combine builds the word from the two loaded source words.
+__device__ static inline int reflect_near(int i, int n)
+{   // scipy 'reflect' for indices at most 2 outside [0, n) (n = 1: everything reflects onto 0)
+    return n < 2 ? 0 : (i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i));
+}
+
+__device__ static inline int64_t ext_src_addr(const FieldParams &p, bool ok, int ez, int ey, int gw, int *meta)
+{
+    const int z = reflect_near(ez - 2, p.nz + 2 * p.pad) - p.pad, y = reflect_near(ey - 2, p.ny + 2 * p.pad) - p.pad;
+    const bool rv = ok && z >= 0 && z < p.nz && y >= 0 && y < p.ny;
+    const bool hv = rv && gw < p.SW32, lv = rv && gw >= 1 && gw - 1 < p.SW32;
+    *meta = (gw & 0xffff) | (hv ? 0x10000 : 0) | (lv ? 0x20000 : 0);
+    // offset of source word gw - 1; an invalid row / word reads word 0 of the volume (the value is discarded)
+    const int64_t row = rv ? ((int64_t)z * p.ny + y) * p.SW32 : 0;
+    return row + (lv ? gw - 1 : (hv ? gw : 0));      // hv && !lv only for gw == 0: then this IS word gw (see combine)
+}
+
+__device__ static inline u32 ext_word_combine(const FieldParams &p, int meta, u32 w_lo, u32 w_hi)
+{
+    const int gw = meta & 0xffff;
+    const bool hv = meta & 0x10000, lv = meta & 0x20000;
+    const u32 hi = hv ? (lv ? w_hi : w_lo) : 0u, lo = lv ? w_lo : 0u;     // without a word gw-1 the first load was word gw
+    const int sh = 4 + p.pad;                                             // ext bit e = data x + 4 + pad
+    u32 v = (hi << sh) | (lo >> (32 - sh));
+    const int Nx = p.nx + 2 * p.pad;
+    // reflected columns: ext bit e = X + 4 takes the data bit of padded column reflect(X) (the pad ring reads as 0)
+    if (gw == 0) {
+#pragma unroll
+        for (int X = -2; X <= -1; X++) {
+            const int x = reflect_near(X, Nx) - p.pad;                    // 1 / 0 (pad 0), 0 / ring (pad 1)
+            const u32 bit = (x >= 0 && x < p.nx) ? (hi >> x) & 1u : 0u;   // x < 32: inside word 0 = hi
+            v = (v & ~(1u << (X + 4))) | (bit << (X + 4));
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const int e = Nx + d + 4;
+        if ((e >> 5) == gw) {
+            const int x = reflect_near(Nx + d, Nx) - p.pad;               // nx-1 / nx-2 (pad 0), ring / nx-1 (pad 1)
+            u32 bit = 0u;
+            if (x >= 0 && x < p.nx) {
+                const int wsrc = x >> 5;                                  // gw or gw - 1 (0 <= e - x <= 7)
+                bit = ((wsrc == gw ? hi : lo) >> (x & 31)) & 1u;
+            }
+            v = (v & ~(1u << (e & 31))) | (bit << (e & 31));
+        }
+    }
+    return (hv || lv) ? v : 0u;
+}
+
+template <bool FROM_BITS>
 __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
                                                                 const FieldParams p)
 {
@@ -108,19 +164,27 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         const int dw = FT_THREADS % WS, drs = FT_THREADS / WS;
         for (int base = 0; base < total; base += FT_BATCH * FT_THREADS) {
             u32 v[FT_BATCH];
+            u32 v2[FROM_BITS ? FT_BATCH : 1];
+            int meta[FROM_BITS ? FT_BATCH : 1];
             int wi = widx, r = rs;
 #pragma unroll
             for (int b = 0; b < FT_BATCH; b++) {
                 const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
                 const int ez = Z0 + slot, ey = Y0 + row, gw = j0 + wi;
                 const bool ok = (base + b * FT_THREADS + tid) < total && ez < p.EZ && ey < p.EY && gw >= 0 && gw < p.EWX32;
-                v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
+                if (FROM_BITS) {      // two unconditional loads of adjacent source words: all of them in flight together
+                    const int64_t a = ext_src_addr(p, ok, ez, ey, gw, &meta[b]);
+                    v[b] = ext32[a];
+                    v2[b] = ext32[a + ((meta[b] & 0x30000) == 0x30000 ? 1 : 0)];
+                } else
+                    v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
                 wi += dw; r += drs;
                 if (wi >= WS) { wi -= WS; r++; }
             }
 #pragma unroll
             for (int b = 0; b < FT_BATCH; b++) {
                 const int idx = base + b * FT_THREADS + tid;
+                if (FROM_BITS) v[b] = ext_word_combine(p, meta[b], v[b], v2[b]);
                 if (idx < total) s_bits[idx] = v[b];
             }
             widx = wi; rs = r;
@@ -322,6 +386,8 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.nzg = (p.Nz + FT_ZG - 1) / FT_ZG;
     p.S = (int)tomo_mc_segments_per_row(Nx, tomo_field_xorg(pad));
     p.NyP = (int)tomo_sign_rows(p.Ny);
+    p.nz = nz; p.ny = ny; p.nx = nx; p.pad = pad;
+    p.SW32 = 2 * (int)tomo_words_per_row(nx);
     p.signs = (u64 *)signs;
     p.gcls = gcls;
     int ntmax = p.NT < FT_MAXT ? p.NT : FT_MAXT;     // tiles of the widest block
@@ -363,6 +429,23 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
     }
     int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg;
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(field_tile_kernel, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)ext, field, p);
+    hipLaunchKernelGGL(field_tile_kernel<false>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)ext, field, p);
+    return tomo_status();
+}
+
+// The same field straight from the plain bit volume (uint64 (nz, ny, ceil(nx / 64)) words): the extended volume is
+// formed on the fly while the block stages its input, so tomo_extend_bits and its 1/8 B per voxel round trip drop out.
+TOMO_API int tomo_field_fill_bits(const uint64_t *bits, float *field, int nz, int ny, int nx, int pad,
+                                  unsigned long long *signs, uint8_t *gcls, void *stream)
+{
+    if (!bits || !field || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1) || ((signs != nullptr) != (gcls != nullptr)))
+        return TOMO_E_ARG;
+    if (((uintptr_t)field & 127u) != 0) return TOMO_E_ARG;
+    FieldParams p;
+    size_t lds = fill_params(p, nz, ny, nx, pad, signs, gcls);
+    int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg;
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(field_tile_kernel<true>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, (hipStream_t)stream,
+                       (const u32 *)bits, field, p);
     return tomo_status();
 }

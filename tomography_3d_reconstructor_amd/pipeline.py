@@ -15,6 +15,9 @@ import torch
 from . import _lib
 
 
+FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -169,9 +172,6 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
     nz, ny, nx = vol.shape
     L = _lib.lib()
     pad = 1 if (manifold and add_padding) else 0
-    ez, ey, ewx = L.tomo_ext_slices(nz, pad), L.tomo_ext_rows(ny, pad), L.tomo_ext_words_per_row(nx, pad)
-    ext = torch.empty((ez, ey, ewx), dtype=torch.int64, device=vol.device)
-    _lib.check(L.tomo_extend_bits(_p(vol.bits), _p(ext), nz, ny, nx, pad, _stream()), "tomo_extend_bits")
     Nz, Ny, Nx = nz + 2 * pad, ny + 2 * pad, nx + 2 * pad
     pitch = L.tomo_field_pitch(nx, pad)
     data = torch.empty((Nz, Ny, pitch), dtype=torch.float32, device=vol.device)
@@ -186,8 +186,16 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
         sbuf = torch.empty(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
         signs = sbuf[: Nz * S * NyP * 4].view(Nz, S, NyP, 4)
         gcls = torch.empty((Nz, NyP // 16, S), dtype=torch.uint8, device=vol.device)
-    _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _p(gcls), _stream()),
-               "tomo_field_fill")
+    if manifold and FIELD_FROM_BITS:
+        # the Gaussian field straight from the bit volume: border rules applied while the kernel stages its input
+        _lib.check(L.tomo_field_fill_bits(_p(vol.bits), _p(data), nz, ny, nx, pad, _p(sbuf), _p(gcls), _stream()),
+                   "tomo_field_fill_bits")
+    else:
+        ez, ey, ewx = L.tomo_ext_slices(nz, pad), L.tomo_ext_rows(ny, pad), L.tomo_ext_words_per_row(nx, pad)
+        ext = torch.empty((ez, ey, ewx), dtype=torch.int64, device=vol.device)
+        _lib.check(L.tomo_extend_bits(_p(vol.bits), _p(ext), nz, ny, nx, pad, _stream()), "tomo_extend_bits")
+        _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _p(gcls), _stream()),
+                   "tomo_field_fill")
     return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5, gcls)
 
 
