@@ -120,3 +120,34 @@ def test_oracle_loader_orders_and_thresholds(tmp_path):
     assert len(masks) == 8 and all(np.array_equal(m, imgs[n] >= 200) for m, n in zip(masks, order))
     masks2, counts2, _ = O.load_masks(str(tmp_path), 200, (True, False, True))
     assert counts2 == (3, 0, 1) and len(masks2) == 4
+
+
+def test_slice_generator_half_ellipsoid_stack(tmp_path, capsys):
+    """Row N3 (parity with OpenCV unpinned): naming, count, deletion of the extremes, shrinking areas, and the stack is
+    what the loader's numeric ordering expects (ellipsoid_slice_generator.py:107-143, simple_generator.py:6-20)."""
+    from PIL import Image
+    from tomography_3d_reconstructor_amd.slice_generator import EllipsoidSliceGenerator, generate_slices_from_mask
+    h, w = 96, 128
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = ((((xx - 60.0) / 40.0) ** 2 + ((yy - 50.0) / 25.0) ** 2) <= 1.0)
+    src = tmp_path / "Section_1"
+    src.mkdir()
+    Image.fromarray(np.where(base, 255, 0).astype(np.uint8), mode="L").save(src / "Mask_Patient_1.png")
+    g = EllipsoidSliceGenerator(str(src / "Mask_Patient_1.png"))
+    p = g.ellipse_params
+    assert abs(p["center"][0] - 60) < 0.5 and abs(p["center"][1] - 50) < 0.5
+    assert abs(p["semi_major_axis"] - 40) < 1.0 and abs(p["semi_minor_axis"] - 25) < 1.0
+    assert np.array_equal(g._generate_slice_at_height(0.0, 25.0), g.middle_slice)
+    assert not g._generate_slice_at_height(30.0, 25.0).any()
+    out0 = tmp_path / "Section_0"
+    generate_slices_from_mask(str(src / "Mask_Patient_1.png"), 6, str(out0), 1, False)       # numbers -6 .. 1, extremes removed
+    assert "Generated 8 slices" in capsys.readouterr().out
+    names = sorted(os.listdir(out0))
+    assert names == sorted("Mask_Patient_%d.png" % n for n in range(-5, 1))
+    areas = {n: int((np.asarray(Image.open(out0 / ("Mask_Patient_%d.png" % n))) > 127).sum()) for n in range(-5, 1)}
+    assert all(areas[n] < areas[n + 1] for n in range(-5, -1)) and areas[-1] <= areas[0] <= int(base.sum())   # grows towards the base mask
+    (tmp_path / "Section_2").mkdir()
+    masks, counts, files = O.load_masks(str(tmp_path), 200)
+    assert counts == (6, 1, 0) and [os.path.basename(f) for f in files][0] == "Mask_Patient_-5.png" and len(masks) == 7
+    full = g.generate_slices(5, str(tmp_path / "full"))
+    assert [os.path.basename(f) for f in full] == ["Mask_%03d.png" % i for i in range(1, 6)]

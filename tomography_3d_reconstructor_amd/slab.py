@@ -43,42 +43,43 @@ class TorchDistComm:
         self.world = td.get_world_size()
         self.device = device
 
-    def send(self, t, dst):
-        t = t.contiguous()
-        hdr = torch.tensor([t.dim()] + list(t.shape) + [0] * (7 - t.dim()), dtype=torch.int64, device=self.device)
-        self.td.send(hdr, dst)
-        if t.numel():
-            self.td.send(t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1), dst)
+    @staticmethod
+    def _bytes(t):
+        return t.reshape(-1) if t.dtype == torch.uint8 else t.view(torch.uint8).reshape(-1)
 
-    def recv(self, src, dtype):
-        hdr = torch.zeros(8, dtype=torch.int64, device=self.device)
-        self.td.recv(hdr, src)
-        h = hdr.cpu().tolist()
-        shape = h[1:1 + h[0]]
-        out = torch.empty(shape, dtype=dtype, device=self.device)
-        if out.numel():
-            buf = out.view(torch.uint8).reshape(-1) if dtype != torch.uint8 else out.reshape(-1)
-            self.td.recv(buf, src)
-        return out
-
-    def exchange(self, to_prev, to_next, dtype):
+    def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
         """Neighbour exchange along z.  `to_prev` goes to rank-1, `to_next` to rank+1; a direction is either used
         by EVERY rank (all pass a tensor; the end ranks' tensor simply has no destination) or by none (all pass
         None).  Returns (from_prev, from_next), None where there is no such neighbour / direction.
-        Even ranks send first, odd ranks receive first: no deadlock with blocking send/recv."""
+        No headers travel: what arrives from rank-1 has the shape of what this rank sends to rank+1 (and vice versa)
+        unless recv_shape_prev / recv_shape_next say otherwise (variable-size lists: exchange the counts first).
+        All sends and receives of one call go out as ONE batch (a grouped RCCL call: both directions at once, no
+        send/recv ordering to deadlock on); empty tensors are skipped on both sides."""
+        td = self.td
         r, w = self.rank, self.world
+        ops, keep = [], []
         from_prev = from_next = None
-        for phase in (0, 1):
-            if (r % 2) == phase:
-                if r + 1 < w and to_next is not None:
-                    self.send(to_next, r + 1)
-                if r - 1 >= 0 and to_prev is not None:
-                    self.send(to_prev, r - 1)
-            else:
-                if r - 1 >= 0 and to_next is not None:
-                    from_prev = self.recv(r - 1, dtype)
-                if r + 1 < w and to_prev is not None:
-                    from_next = self.recv(r + 1, dtype)
+        if to_next is not None:
+            if r + 1 < w and to_next.numel():
+                keep.append(to_next.contiguous())
+                ops.append(td.P2POp(td.isend, self._bytes(keep[-1]), r + 1))
+            if r - 1 >= 0:
+                shape = tuple(recv_shape_prev) if recv_shape_prev is not None else tuple(to_next.shape)
+                from_prev = torch.empty(shape, dtype=dtype, device=self.device)
+                if from_prev.numel():
+                    ops.append(td.P2POp(td.irecv, self._bytes(from_prev), r - 1))
+        if to_prev is not None:
+            if r - 1 >= 0 and to_prev.numel():
+                keep.append(to_prev.contiguous())
+                ops.append(td.P2POp(td.isend, self._bytes(keep[-1]), r - 1))
+            if r + 1 < w:
+                shape = tuple(recv_shape_next) if recv_shape_next is not None else tuple(to_prev.shape)
+                from_next = torch.empty(shape, dtype=dtype, device=self.device)
+                if from_next.numel():
+                    ops.append(td.P2POp(td.irecv, self._bytes(from_next), r + 1))
+        if ops:
+            for q in td.batch_isend_irecv(ops):
+                q.wait()
         return from_prev, from_next
 
     def all_gather(self, t):
@@ -100,7 +101,7 @@ class ThreadComm:
     def recv(self, src, dtype):
         return self.q[(src, self.rank)].get(timeout=120)
 
-    def exchange(self, to_prev, to_next, dtype):
+    def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
         r, w = self.rank, self.world
         if r + 1 < w and to_next is not None:
             self.send(to_next, r + 1)
@@ -329,7 +330,11 @@ class SlabJob:
             top = torch.zeros(nv, dtype=torch.bool, device=dev)
         top_idx = torch.nonzero(top).reshape(-1)
         keep_idx = torch.nonzero(~top).reshape(-1)
-        from_prev, _ = c.exchange(None, vpos[top_idx].contiguous(), torch.float32)
+        # how many shared-plane vertices arrive from below, then the vertices themselves
+        n_top = int(top_idx.numel())
+        cnt_prev, _ = c.exchange(None, torch.tensor([n_top], dtype=torch.int64, device=dev), torch.int64)
+        n_from_prev = int(cnt_prev.item()) if cnt_prev is not None else 0
+        from_prev, _ = c.exchange(None, vpos[top_idx].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
         own = vpos[keep_idx]
         n_own = own.shape[0]
         allv = torch.cat([own, from_prev.reshape(-1, 3)], 0) if from_prev is not None else own
@@ -338,7 +343,7 @@ class SlabJob:
         else:
             uniq, rank = allv, torch.zeros(0, dtype=torch.int32, device=dev)
         # indices of the lower neighbour's top-plane vertices go back down
-        _, ids_next = c.exchange(rank[n_own:].contiguous(), None, torch.int32)
+        _, ids_next = c.exchange(rank[n_own:].contiguous(), None, torch.int32, recv_shape_next=(n_top,))
         counts = c.all_gather(torch.tensor([uniq.shape[0]], dtype=torch.int64, device=dev))
         counts = [int(x.item()) for x in counts]
         offs = np.concatenate([[0], np.cumsum(counts)])
