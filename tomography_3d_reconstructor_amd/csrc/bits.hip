@@ -649,9 +649,19 @@ static int morph_wave_launch(const u64 *in, u64 *out, int nz, int ny, int nx, in
 {
     const int rows_own = 64 - 2 * H;
     const int nxt = (wx + FW_W - 1) / FW_W, nyt = (ny + rows_own - 1) / rows_own;
-    int zchunk = nz;
-    while (zchunk > 16 && (int64_t)nxt * nyt * ceil_div64(nz, zchunk) < 2048) zchunk = (zchunk + 1) / 2;   // two waves per SIMD
-    const int64_t nwaves = (int64_t)nxt * nyt * ceil_div64(nz, zchunk);
+    // z chunks: the kernel holds two waves per SIMD (VGPR-bound) and a wave's time is its slice count, so the waves
+    // should fill the machine's wave slots in ONE round -- a second, mostly empty round costs as much as the first.
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = (cus > 0 ? cus : 256) * 4 * 2;
+    }
+    const int64_t cols = (int64_t)nxt * nyt;
+    int64_t chunks = cols >= slots ? 1 : slots / cols;
+    int zchunk = (int)ceil_div64(nz, chunks);
+    if (zchunk < 16) zchunk = nz < 16 ? nz : 16;             // below this the 2 H halo slices dominate
+    const int64_t nwaves = cols * ceil_div64(nz, zchunk);
     const int64_t blocks = ceil_div64(nwaves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
 #define FW_GO(OPSC) hipLaunchKernelGGL((morph_wave_kernel<H, OPSC>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, nz, ny, nx, \
