@@ -48,6 +48,7 @@ struct FieldParams {
     int EZ, EY, EWX32;              // extended bit volume: slices, rows, 32-bit words per row
     int64_t pitch;
     int nxc, ntr, nzg;              // blocks per row, tile rows, slice groups
+    int tp;                         // tile positions (tile index + 7) per block along x: a multiple of 8, <= FT_MAXT
     int nz, ny, nx, pad, SW32;      // (FROM_BITS) the plain bit volume the input is derived from: dims, 32-bit words per row
     u64 *signs;                     // sign records [Nz][S][NyP][4] (may be null)
     unsigned char *gcls;            // class of every group of 16 rows of records [Nz][NyP / 16][S]: 0 / 1 = all bits 0 / 1
@@ -144,9 +145,10 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     const int bx = (int)(lin % (unsigned)p.nxc);
     const int tr = (int)((lin / (unsigned)p.nxc) % (unsigned)p.ntr);
     const int zg = (int)(lin / ((unsigned)p.nxc * (unsigned)p.ntr));
-    // tiles j0 .. j0+nt-1; chunk boundaries fall on marching-cubes segment boundaries ((j + 7) % 8 == 0)
-    const int j0 = bx == 0 ? 0 : FT_MAXT * bx - 7;
-    const int jend = FT_MAXT * bx + FT_MAXT - 7 < p.NT ? FT_MAXT * bx + FT_MAXT - 7 : p.NT;
+    // tiles j0 .. j0+nt-1; chunk boundaries fall on marching-cubes segment boundaries ((j + 7) % 8 == 0) and the
+    // chunks of a wide row are equally long (p.tp positions each)
+    const int j0 = bx == 0 ? 0 : p.tp * bx - 7;
+    const int jend = p.tp * bx + p.tp - 7 < p.NT ? p.tp * bx + p.tp - 7 : p.NT;
     const int nt = jend - j0;
     const int joff = (j0 + 7) & 7;                  // byte position of tile j0 in its segment's record words
     const int WS = nt + 1;                          // staged words per row: ext words j0 .. j0+nt
@@ -382,6 +384,7 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.pitch = tomo_field_pitch(nx, pad);
     p.NT = (int)(p.pitch / 32);
     p.nxc = (p.NT + 7 + FT_MAXT - 1) / FT_MAXT;
+    p.tp = ((p.NT + 7 + p.nxc - 1) / p.nxc + 7) / 8 * 8;          // balanced chunks, still a multiple of 8 and <= FT_MAXT
     p.ntr = (p.Ny + FT_ROWS - 1) / FT_ROWS;
     p.nzg = (p.Nz + FT_ZG - 1) / FT_ZG;
     p.S = (int)tomo_mc_segments_per_row(Nx, tomo_field_xorg(pad));
@@ -390,7 +393,7 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.SW32 = 2 * (int)tomo_words_per_row(nx);
     p.signs = (u64 *)signs;
     p.gcls = gcls;
-    int ntmax = p.NT < FT_MAXT ? p.NT : FT_MAXT;     // tiles of the widest block
+    int ntmax = p.NT < p.tp ? p.NT : p.tp;           // tiles of the widest block
     int WS = ntmax + 1;
     size_t words = (((size_t)(FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~(size_t)1);
     p.SB = (ntmax + 7 + 7) & ~7;

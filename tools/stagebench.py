@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""Per-stage wall time (HIP events) of one pass of the hot path on the 1024^3 ellipsoid: python tools/stagebench.py [N]"""
+"""Per-stage wall time (HIP events) of one pass of the hot path on an ellipsoid: python tools/stagebench.py [N | NZ NY NX]"""
 import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tomography_3d_reconstructor_amd import pipeline  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+if len(sys.argv) > 3:
+    nz, ny, nx = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+else:
+    nz = ny = nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda:0")
-mask = pipeline.ellipsoid_mask(n, n, n, dev).view(torch.uint8)
-depths = np.full(n, 1.0)
+mask = pipeline.ellipsoid_mask(nz, ny, nx, dev).view(torch.uint8)
+depths = np.full(nz, 1.0)
 stages = ["pack", "close", "smooth", "field", "mc", "finalize", "unique"]
 acc = {s: [] for s in stages}
 for it in range(6):
