@@ -59,23 +59,39 @@ __device__ static inline u32 nonzero_nibble(u32 w)
     return ((h >> 7) * 0x10204080u) >> 28;
 }
 
+#ifndef PACK_U
+#define PACK_U 2        // 1024-voxel units per wave, their 16-byte loads in flight together (1: 4.8, 2: 5.2, 4: 5.0, 8: 4.6 TB/s)
+#endif
 __global__ __launch_bounds__(256) void pack16_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits,
                                                      int64_t rows, int nx, int wx, int groups)
 {
     const int lane = threadIdx.x & 63;
-    int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= rows * groups) return;
-    int64_t row = wid / groups;
-    int g = (int)(wid - row * groups);
-    int x = g * 1024 + lane * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (x < nx) v = *(const uint4 *)(mask + row * (int64_t)nx + x);
-    u32 piece = nonzero_nibble(v.x) | (nonzero_nibble(v.y) << 4) | (nonzero_nibble(v.z) << 8) | (nonzero_nibble(v.w) << 12);
-    u64 w = (u64)piece << (16 * (lane & 3));
-    w |= __shfl_xor(w, 1, 64);
-    w |= __shfl_xor(w, 2, 64);
-    int word = g * 16 + (lane >> 2);
-    if ((lane & 3) == 0 && word < wx) bits[row * (int64_t)wx + word] = w;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t units = rows * groups, u0 = wid * PACK_U;
+    if (u0 >= units) return;
+    uint4 v[PACK_U];
+#pragma unroll
+    for (int i = 0; i < PACK_U; i++) {
+        const int64_t u = u0 + i;
+        const int64_t row = u / groups;
+        const int x = (int)(u - row * groups) * 1024 + lane * 16;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (u < units && x < nx) v[i] = *(const uint4 *)(mask + row * (int64_t)nx + x);
+    }
+#pragma unroll
+    for (int i = 0; i < PACK_U; i++) {
+        const int64_t u = u0 + i;
+        if (u >= units) break;
+        const int64_t row = u / groups;
+        const int g = (int)(u - row * groups);
+        u32 piece = nonzero_nibble(v[i].x) | (nonzero_nibble(v[i].y) << 4) | (nonzero_nibble(v[i].z) << 8) |
+                    (nonzero_nibble(v[i].w) << 12);
+        u64 w = (u64)piece << (16 * (lane & 3));
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        int word = g * 16 + (lane >> 2);
+        if ((lane & 3) == 0 && word < wx) bits[row * (int64_t)wx + word] = w;
+    }
 }
 
 TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, void *stream)
@@ -88,8 +104,8 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
     int64_t blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     if (nx % 16 == 0 && (((uintptr_t)mask) & 15) == 0)
-        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, rows,
-                           nx, wx, groups);
+        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)ceil_div64(ceil_div64(waves, PACK_U), 4)), dim3(256), 0,
+                           (hipStream_t)stream, mask, (u64 *)bits, rows, nx, wx, groups);
     else
         hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, rows,
                            nx, wx, groups);
