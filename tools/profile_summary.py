@@ -4,7 +4,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 out, tag = sys.argv[1], sys.argv[2]
-PASSES = 7            # --steps 5 --warmup 2
+PASSES = 9            # 2 allocator-priming passes + --warmup 2 + --steps 5
 
 
 def one(pattern):
@@ -58,7 +58,7 @@ pmcj = {"kernel": fk, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu
 json.dump(pmcj, open(os.path.join(out, "%s_field_pmc.json" % tag), "w"), indent=1)
 
 md = ["# Round profile `%s` -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`\n" % tag,
-      "MI355X (gfx950), 1024^3 ellipsoid, 7 passes of the hot path (2 warm-up + 5 timed).  Full CSV: `%s_bench_kernel_stats.csv`.\n" % tag,
+      "MI355X (gfx950), 1024^3 ellipsoid, 9 passes of the hot path (2 priming + 2 warm-up + 5 timed).  Full CSV: `%s_bench_kernel_stats.csv`.\n" % tag,
       "Bench line of the profiled run: `%s`\n" % last_json(os.path.join(out, "bench_trace.log")),
       "Bench line, un-profiled (`python bench.py`): `%s`\n" % last_json(os.path.join(out, "bench_plain.log")),
       "\n| kernel | calls | avg us | ms per pass | % |\n|---|---|---|---|---|"]
@@ -69,7 +69,7 @@ md.append("\n## PMC passes (separate runs of the same command: `--pmc FETCH_SIZE
 md.append("Calibration: `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
           "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below.  WRITE_SIZE is exact.\n")
 md.append("| kernel | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM bytes = 2*FETCH + WRITE |\n|---|---|---|---|")
-for sub in ("pack16_kernel", "morph_fused_kernel", "extend_kernel", fk, "mc_classify_bits_kernel", "mc_emit_kernel"):
+for sub in ("pack16_kernel", "morph_wave_kernel<4, 6>", "morph_wave_kernel<4, 5>", fk, "mc_classify_bits_kernel", "mc_emit_kernel"):
     a, b = find(fetch, sub), find(write, sub)
     if a is not None and b is not None:
         md.append("| `%s` | %.0f | %.0f | %.3e |" % (sub, a, b, (2 * a + b) * 1024))
