@@ -71,56 +71,10 @@ extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
 
 // One 32-bit word of the EXTENDED bit volume (slice ez, row ey, word gw) from the plain bit volume -- what extend_kernel
 // (bits.hip) would have stored there: reflect of the padded array along z and y, a funnel shift by 4 + pad bits along x,
-// and the four reflected columns X = -2, -1, Nx, Nx+1.  Split in two so that the staging loop can issue ALL its loads
-// before it touches any of them: ext_src_addr gives the (always valid) offset of source word gw-1 / gw and the validity
-// bits, ext_word_combine builds the word from the two loaded source words.
+// and the four reflected columns X = -2, -1, Nx, Nx+1.  Done inside the staging loop of the kernel (FROM_BITS).
 __device__ static inline int reflect_near(int i, int n)
 {   // scipy 'reflect' for indices at most 2 outside [0, n) (n = 1: everything reflects onto 0)
     return n < 2 ? 0 : (i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i));
-}
-
-__device__ static inline int64_t ext_src_addr(const FieldParams &p, bool ok, int ez, int ey, int gw, int *meta)
-{
-    const int z = reflect_near(ez - 2, p.nz + 2 * p.pad) - p.pad, y = reflect_near(ey - 2, p.ny + 2 * p.pad) - p.pad;
-    const bool rv = ok && z >= 0 && z < p.nz && y >= 0 && y < p.ny;
-    const bool hv = rv && gw < p.SW32, lv = rv && gw >= 1 && gw - 1 < p.SW32;
-    *meta = (gw & 0xffff) | (hv ? 0x10000 : 0) | (lv ? 0x20000 : 0);
-    // offset of source word gw - 1; an invalid row / word reads word 0 of the volume (the value is discarded)
-    const int64_t row = rv ? ((int64_t)z * p.ny + y) * p.SW32 : 0;
-    return row + (lv ? gw - 1 : (hv ? gw : 0));      // hv && !lv only for gw == 0: then this IS word gw (see combine)
-}
-
-__device__ static inline u32 ext_word_combine(const FieldParams &p, int meta, u32 w_lo, u32 w_hi)
-{
-    const int gw = meta & 0xffff;
-    const bool hv = meta & 0x10000, lv = meta & 0x20000;
-    const u32 hi = hv ? (lv ? w_hi : w_lo) : 0u, lo = lv ? w_lo : 0u;     // without a word gw-1 the first load was word gw
-    const int sh = 4 + p.pad;                                             // ext bit e = data x + 4 + pad
-    u32 v = (hi << sh) | (lo >> (32 - sh));
-    const int Nx = p.nx + 2 * p.pad;
-    // reflected columns: ext bit e = X + 4 takes the data bit of padded column reflect(X) (the pad ring reads as 0)
-    if (gw == 0) {
-#pragma unroll
-        for (int X = -2; X <= -1; X++) {
-            const int x = reflect_near(X, Nx) - p.pad;                    // 1 / 0 (pad 0), 0 / ring (pad 1)
-            const u32 bit = (x >= 0 && x < p.nx) ? (hi >> x) & 1u : 0u;   // x < 32: inside word 0 = hi
-            v = (v & ~(1u << (X + 4))) | (bit << (X + 4));
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 2; d++) {
-        const int e = Nx + d + 4;
-        if ((e >> 5) == gw) {
-            const int x = reflect_near(Nx + d, Nx) - p.pad;               // nx-1 / nx-2 (pad 0), ring / nx-1 (pad 1)
-            u32 bit = 0u;
-            if (x >= 0 && x < p.nx) {
-                const int wsrc = x >> 5;                                  // gw or gw - 1 (0 <= e - x <= 7)
-                bit = ((wsrc == gw ? hi : lo) >> (x & 31)) & 1u;
-            }
-            v = (v & ~(1u << (e & 31))) | (bit << (e & 31));
-        }
-    }
-    return (hv || lv) ? v : 0u;
 }
 
 template <bool FROM_BITS>
@@ -157,36 +111,80 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     u32 *const s_ror = s_bits + FT_SLOTS * FT_SROWS * WS, *const s_rand = s_ror + FT_SLOTS * WS;
     unsigned char *const s_sign = (unsigned char *)(s_dyn + (((FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~1));
 
-    // ---- stage the block's input bits: flat copy of [slot][row][word] (slot = ext slice Z0 + slot, row = ext
-    //      row Y0 + row, word = ext word j0 + widx); everything outside the extended volume reads as zero
-    {
+    // ---- stage the block's input bits [slot][row][word] (slot = ext slice Z0 + slot, row = ext row Y0 + row, word = ext
+    //      word j0 + widx); everything outside the extended volume reads as zero
+    if (FROM_BITS) {
+        // Straight from the plain bit volume.  A thread keeps ONE word column and walks down the (slot, row) pairs, so
+        // everything that depends on x -- which source words exist, the reflected columns -- is computed once; per row
+        // there is the reflect of (z, y), two unconditional loads (all of a batch in flight together) and a funnel shift.
+        const int RG = FT_THREADS / WS;                       // rows handled per sweep of the block
+        const int rg = tid / WS, widx = tid - rg * WS;
+        const int gw = j0 + widx;
+        const bool colv = rg < RG && gw < p.EWX32;
+        const bool hv = gw < p.SW32, lv = gw >= 1 && gw - 1 < p.SW32;
+        const int sh = 4 + p.pad;                             // ext bit e = data x + 4 + pad
+        const int Nxp = p.nx + 2 * p.pad;
+        // reflected columns X = -2, -1, Nx, Nx+1 (ext bit X + 4): (bit position in this word, source word hi/lo, source bit)
+        int nfix = 0, fpos[4], fsrc[4], fbit[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int X = q < 2 ? q - 2 : Nxp + q - 2;
+            const int e = X + 4;
+            if ((e >> 5) == gw) {
+                const int x = reflect_near(X, Nxp) - p.pad;    // data column the bit is copied from (outside: the pad ring, 0)
+                const bool ok = x >= 0 && x < p.nx;
+                fpos[nfix] = e & 31;
+                fsrc[nfix] = ok ? ((x >> 5) == gw ? 1 : 0) : -1;       // 1: word gw ("hi"), 0: word gw - 1 ("lo"), -1: zero
+                fbit[nfix] = x & 31;
+                nfix++;
+            }
+        }
+        const int nrs = FT_SLOTS * FT_SROWS;
+        const int Nzp = p.nz + 2 * p.pad, Nyp = p.ny + 2 * p.pad;
+        for (int r0 = rg; r0 < nrs; r0 += RG * FT_BATCH) {
+            u32 vh[FT_BATCH], vl[FT_BATCH];
+            bool rv[FT_BATCH];
+#pragma unroll
+            for (int b = 0; b < FT_BATCH; b++) {
+                const int r = r0 + b * RG;
+                const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
+                const int z = reflect_near(Z0 + slot - 2, Nzp) - p.pad, y = reflect_near(Y0 + row - 2, Nyp) - p.pad;
+                rv[b] = colv && r < nrs && Z0 + slot < p.EZ && Y0 + row < p.EY && z >= 0 && z < p.nz && y >= 0 && y < p.ny;
+                const int64_t base = rv[b] ? ((int64_t)z * p.ny + y) * p.SW32 : 0;
+                vh[b] = ext32[base + ((rv[b] && hv) ? gw : 0)];
+                vl[b] = ext32[base + ((rv[b] && lv) ? gw - 1 : 0)];
+            }
+#pragma unroll
+            for (int b = 0; b < FT_BATCH; b++) {
+                const int r = r0 + b * RG;
+                const u32 hi = (rv[b] && hv) ? vh[b] : 0u, lo = (rv[b] && lv) ? vl[b] : 0u;
+                u32 v = (hi << sh) | (lo >> (32 - sh));
+                for (int q = 0; q < nfix; q++) {
+                    const u32 bit = fsrc[q] < 0 ? 0u : (((fsrc[q] ? hi : lo) >> fbit[q]) & 1u);
+                    v = (v & ~(1u << fpos[q])) | (bit << fpos[q]);
+                }
+                if (rg < RG && r < nrs) s_bits[r * WS + widx] = v;
+            }
+        }
+    } else {
         const int total = FT_SLOTS * FT_SROWS * WS;
-        int i = tid;
-        int widx = i % WS, rs = i / WS;             // rs = slot * FT_SROWS + row
+        int widx = tid % WS, rs = tid / WS;             // rs = slot * FT_SROWS + row
         const int dw = FT_THREADS % WS, drs = FT_THREADS / WS;
         for (int base = 0; base < total; base += FT_BATCH * FT_THREADS) {
             u32 v[FT_BATCH];
-            u32 v2[FROM_BITS ? FT_BATCH : 1];
-            int meta[FROM_BITS ? FT_BATCH : 1];
             int wi = widx, r = rs;
 #pragma unroll
             for (int b = 0; b < FT_BATCH; b++) {
                 const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
                 const int ez = Z0 + slot, ey = Y0 + row, gw = j0 + wi;
                 const bool ok = (base + b * FT_THREADS + tid) < total && ez < p.EZ && ey < p.EY && gw >= 0 && gw < p.EWX32;
-                if (FROM_BITS) {      // two unconditional loads of adjacent source words: all of them in flight together
-                    const int64_t a = ext_src_addr(p, ok, ez, ey, gw, &meta[b]);
-                    v[b] = ext32[a];
-                    v2[b] = ext32[a + ((meta[b] & 0x30000) == 0x30000 ? 1 : 0)];
-                } else
-                    v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
+                v[b] = ok ? ext32[((int64_t)ez * p.EY + ey) * p.EWX32 + gw] : 0u;
                 wi += dw; r += drs;
                 if (wi >= WS) { wi -= WS; r++; }
             }
 #pragma unroll
             for (int b = 0; b < FT_BATCH; b++) {
                 const int idx = base + b * FT_THREADS + tid;
-                if (FROM_BITS) v[b] = ext_word_combine(p, meta[b], v[b], v2[b]);
                 if (idx < total) s_bits[idx] = v[b];
             }
             widx = wi; rs = r;
