@@ -85,6 +85,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     __shared__ unsigned char s_cls[FT_ZG][FT_SBMAX];
     __shared__ unsigned short s_list[FT_ZG * FT_MAXT];
     __shared__ int s_nmixed;
+    __shared__ int s_zy[FT_SLOTS + FT_SROWS];       // (FROM_BITS) source slice / row of the staged slots / rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = FT_THREADS / 64;
     if (tid < 18) {
         int c = tid / 9, s2 = (tid / 3) % 3, s1 = tid % 3;
@@ -124,23 +125,31 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         const bool hv = gw < p.SW32, lv = gw >= 1 && gw - 1 < p.SW32;
         const int sh = 4 + p.pad;                             // ext bit e = data x + 4 + pad
         const int Nxp = p.nx + 2 * p.pad;
-        // reflected columns X = -2, -1, Nx, Nx+1 (ext bit X + 4): (bit position in this word, source word hi/lo, source bit)
-        int nfix = 0, fpos[4], fsrc[4], fbit[4];
+        // reflected columns X = -2, -1, Nx, Nx+1 (ext bit X + 4): bit `fsrc` of the 64-bit pair (word gw : word gw-1) is
+        // OR-ed in at position `fpos` (the funnel shift leaves zeros there: left of the data and in its tail)
+        int fpos[4], fsrc[4];
+        u32 fen[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int X = q < 2 ? q - 2 : Nxp + q - 2;
             const int e = X + 4;
-            if ((e >> 5) == gw) {
-                const int x = reflect_near(X, Nxp) - p.pad;    // data column the bit is copied from (outside: the pad ring, 0)
-                const bool ok = x >= 0 && x < p.nx;
-                fpos[nfix] = e & 31;
-                fsrc[nfix] = ok ? ((x >> 5) == gw ? 1 : 0) : -1;       // 1: word gw ("hi"), 0: word gw - 1 ("lo"), -1: zero
-                fbit[nfix] = x & 31;
-                nfix++;
-            }
+            const int x = reflect_near(X, Nxp) - p.pad;        // data column the bit is copied from (outside: the pad ring, 0)
+            const bool on = (e >> 5) == gw && x >= 0 && x < p.nx;
+            fpos[q] = e & 31;
+            fsrc[q] = on ? x - 32 * (gw - 1) : 0;              // 0 .. 63 (e - x <= 7)
+            fen[q] = on ? 1u : 0u;
         }
+        // source slice / row of every staged slot / row (-1: outside the volume), once per block
+        if (tid < FT_SLOTS) {
+            const int z = reflect_near(Z0 + tid - 2, p.nz + 2 * p.pad) - p.pad;
+            s_zy[tid] = (Z0 + tid < p.EZ && z >= 0 && z < p.nz) ? z : -1;
+        } else if (tid < FT_SLOTS + FT_SROWS) {
+            const int row = tid - FT_SLOTS;
+            const int y = reflect_near(Y0 + row - 2, p.ny + 2 * p.pad) - p.pad;
+            s_zy[tid] = (Y0 + row < p.EY && y >= 0 && y < p.ny) ? y : -1;
+        }
+        __syncthreads();
         const int nrs = FT_SLOTS * FT_SROWS;
-        const int Nzp = p.nz + 2 * p.pad, Nyp = p.ny + 2 * p.pad;
         for (int r0 = rg; r0 < nrs; r0 += RG * FT_BATCH) {
             u32 vh[FT_BATCH], vl[FT_BATCH];
             bool rv[FT_BATCH];
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
             for (int b = 0; b < FT_BATCH; b++) {
                 const int r = r0 + b * RG;
                 const int slot = r / FT_SROWS, row = r - slot * FT_SROWS;
-                const int z = reflect_near(Z0 + slot - 2, Nzp) - p.pad, y = reflect_near(Y0 + row - 2, Nyp) - p.pad;
-                rv[b] = colv && r < nrs && Z0 + slot < p.EZ && Y0 + row < p.EY && z >= 0 && z < p.nz && y >= 0 && y < p.ny;
+                const int z = r < nrs ? s_zy[slot] : -1, y = r < nrs ? s_zy[FT_SLOTS + row] : -1;
+                rv[b] = colv && z >= 0 && y >= 0;
                 const int64_t base = rv[b] ? ((int64_t)z * p.ny + y) * p.SW32 : 0;
                 vh[b] = ext32[base + ((rv[b] && hv) ? gw : 0)];
                 vl[b] = ext32[base + ((rv[b] && lv) ? gw - 1 : 0)];
@@ -158,11 +167,10 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
             for (int b = 0; b < FT_BATCH; b++) {
                 const int r = r0 + b * RG;
                 const u32 hi = (rv[b] && hv) ? vh[b] : 0u, lo = (rv[b] && lv) ? vl[b] : 0u;
+                const u64 pair = ((u64)hi << 32) | lo;
                 u32 v = (hi << sh) | (lo >> (32 - sh));
-                for (int q = 0; q < nfix; q++) {
-                    const u32 bit = fsrc[q] < 0 ? 0u : (((fsrc[q] ? hi : lo) >> fbit[q]) & 1u);
-                    v = (v & ~(1u << fpos[q])) | (bit << fpos[q]);
-                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) v |= ((u32)(pair >> fsrc[q]) & fen[q]) << fpos[q];
                 if (rg < RG && r < nrs) s_bits[r * WS + widx] = v;
             }
         }
