@@ -201,7 +201,7 @@ def raw_mesh_as_triangles(mesh):
     vpos = mesh.vpos.cpu().numpy()
     idx = mesh.faces32.cpu().numpy()
     assert np.all(np.diff(vkey) > 0), "vertex keys must be strictly ascending"
-    assert int(mesh._err[3].item()) == 0
+    assert int(mesh._stats[7].item()) == 0
     assert idx.min() >= 0 and idx.max() < len(vpos)
     return vpos[idx], vpos
 
