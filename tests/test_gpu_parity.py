@@ -429,30 +429,36 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 
 def test_unique_one_sort_path_detects_disorder_and_falls_back(dev):
-    """tomo_mesh_unique_presorted is exact only for rows whose equal-(z, y) runs ascend in x; it must count every
-    violation, and pipeline.ensure_manifold_mesh must then fall back to the two-sort path: np.unique either way."""
+    """tomo_mesh_unique_presorted is exact only for rows in marching-cubes order; it must count every place where its
+    result descends, and pipeline.ensure_manifold_mesh must then fall back to the two-sort path: np.unique either way."""
     rng = np.random.default_rng(9)
     L = _lib.lib()
     for ordered in (True, False):
         v = rng.integers(0, 6, (5000, 3)).astype(np.float32) * np.float32(0.37)
-        if ordered:     # marching-cubes-like: sorted by (z, y), x ascending inside the runs, duplicates kept
+        if ordered:     # marching-cubes-like: plane vertices of slice Z = index of the z value, rows sorted, duplicates kept
             v = v[np.lexsort((v[:, 2], v[:, 1], v[:, 0]))]
+            zidx = np.searchsorted(np.unique(v[:, 0]), v[:, 0]).astype(np.int64)
+            key = (zidx << 22)                                   # Ny = 1, slot 0: bucket 2 Z, sub-key y
+        else:
+            key = np.zeros(len(v), np.int64)                     # everything in one bucket, sorted by y only
         f = rng.integers(0, len(v), (7000, 3)).astype(np.int32)
-        vt, ft = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+        vt, ft, kt = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev), torch.from_numpy(key).to(dev)
         totals = torch.zeros(4, dtype=torch.int64, device=dev)
         uniq = torch.empty_like(vt)
         rank = torch.empty(len(v), dtype=torch.int32, device=dev)
         wsb = L.tomo_mesh_unique_workspace_bytes(len(v))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.check(L.tomo_mesh_unique_presorted(vt.data_ptr(), len(v), uniq.data_ptr(), rank.data_ptr(), totals.data_ptr(),
-                                                ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream), "presorted")
+        _lib.check(L.tomo_mesh_unique_presorted(vt.data_ptr(), kt.data_ptr(), len(v), 1, uniq.data_ptr(), rank.data_ptr(),
+                                                totals.data_ptr(), ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream),
+                   "presorted")
         nviol = int(totals[2].item())
         assert (nviol == 0) == ordered
         eu, einv = np.unique(v, axis=0, return_inverse=True)
         if ordered:
             assert np.array_equal(uniq[: int(totals[0].item())].cpu().numpy(), eu)
             assert np.array_equal(rank.cpu().numpy(), einv.reshape(-1))
-        mesh = pipeline.RawMesh(None, vt, ft)
+        mesh = pipeline.RawMesh(kt, vt, ft)
+        mesh._ny = 1
         gv, gf = pipeline.ensure_manifold_mesh(mesh)
         ev, ef = O.ensure_manifold_mesh(v, f)
         assert np.array_equal(gv.cpu().numpy(), ev) and np.array_equal(gf.cpu().numpy(), ef)

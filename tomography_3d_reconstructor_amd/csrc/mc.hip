@@ -27,6 +27,7 @@
 
 #define SEG 256
 #define KEY_XBITS 20
+static_assert(KEY_XBITS + 2 == TOMO_KEY_ROW_SHIFT, "key layout shared with mesh.hip");
 
 struct McGrid {
     int Nz, Ny, Nx;

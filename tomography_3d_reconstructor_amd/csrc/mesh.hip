@@ -71,19 +71,25 @@ __global__ __launch_bounds__(256) void uq_gather_kernel(const float *__restrict_
     kzy[i] = ((u64)fkey32(p[0]) << 32) | (u64)fkey32(p[1]);
 }
 
-// (z, y) keys of the rows in their given order (the one-sort path)
-__global__ __launch_bounds__(256) void uq_keys_zy_kernel(const float *__restrict__ vpos, int64_t nv, u64 *__restrict__ kzy,
-                                                         u32 *__restrict__ idx)
+// 48-bit keys of the one-sort path: (bucket, sub).  bucket = 2 Z for a vertex in slice plane Z of its owner voxel
+// (x- / y-edge: sub = y), 2 Z + 1 for a vertex between planes Z and Z + 1 (z-edge or cell centre: sub = z).
+__global__ __launch_bounds__(256) void uq_keys_bucket_kernel(const float *__restrict__ vpos, const u64 *__restrict__ vkey,
+                                                             int64_t nv, int key_row_shift, int Ny, u64 *__restrict__ keys,
+                                                             u32 *__restrict__ idx)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
+    const u64 k = vkey[i];
+    const int slot = (int)(k & 3ull);
+    const u64 Z = (k >> key_row_shift) / (u64)Ny;
     const float *p = vpos + 3 * i;
-    kzy[i] = ((u64)fkey32(p[0]) << 32) | (u64)fkey32(p[1]);
+    const u64 bucket = 2ull * Z + (slot >= 2 ? 1ull : 0ull);
+    keys[i] = (bucket << 32) | (u64)fkey32(slot >= 2 ? p[0] : p[1]);
     idx[i] = (u32)i;
 }
 
 // head[i] = row idx[i] differs from row idx[i-1]; with `violations` also counts the places where two consecutive
-// rows have equal (z, y) but DEscending x (the one-sort path is only valid when there are none)
+// rows DEscend in the lexicographic (z, y, x) order (the one-sort path is only valid when there are none)
 __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__ vpos, int64_t nv,
                                                        const u32 *__restrict__ idx, u32 *__restrict__ head,
                                                        u64 *__restrict__ violations)
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__
     if (i > 0) {
         const float *a = vpos + 3 * (int64_t)idx[i], *b = vpos + 3 * (int64_t)idx[i - 1];
         h = (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
-        if (violations && a[0] == b[0] && a[1] == b[1] && a[2] < b[2]) atomicAdd(violations, 1ull);
+        if (violations && (a[0] < b[0] || (a[0] == b[0] && (a[1] < b[1] || (a[1] == b[1] && a[2] < b[2])))))
+            atomicAdd(violations, 1ull);
     }
     head[i] = h;
 }
@@ -176,16 +183,20 @@ TOMO_API int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_
     return tomo_status();
 }
 
-// One-sort variant for rows that arrive in marching-cubes order (owner voxel z, y, x, then slot): rows with equal
-// (z, y) are then almost always already ascending in x -- x-edge vertices of a row ascend with the owner's x, and so do
-// y- / z-edge vertices that share their fractional coordinate -- so ONE stable sort on (z, y) yields the lexicographic
-// order and the 32-bit x sort is skipped.  "Almost": a float32 rounding coincidence can put a later row before an
-// earlier one; every such place is counted in totals[2] and the caller must then redo the call with tomo_mesh_unique
-// (the result is exact if and only if totals[2] == 0).  Same workspace size.
-TOMO_API int tomo_mesh_unique_presorted(const float *vpos, int64_t nv, float *uniq, int32_t *rank,
-                                        unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
+// One-sort variant for rows that arrive in marching-cubes order (owner voxel z, y, x, then slot) together with their
+// vertex keys.  In that order the vertices of a slice plane Z come before the vertices between planes Z and Z + 1, inside
+// a plane the rows ascend, inside a row the x-edge vertices (y = the row) ascend in x and precede the y-edge vertices, and
+// vertices that share their fractional coordinate ascend in the other two.  So ONE stable radix sort on a 48-bit key
+// (bucket 2 Z / 2 Z + 1, then y inside a plane or z between planes) yields the lexicographic order -- 6 digit passes
+// instead of the 12 of the general two-sort path.  "Almost": float32 rounding (a fractional coordinate landing exactly
+// on a plane / row value) or a zero slice depth can break it; every place where the result descends is counted in
+// totals[2] and the caller must then redo the call with tomo_mesh_unique (exact if and only if totals[2] == 0).
+// vkey: the keys tomo_mc_emit wrote (row << key_row_shift | x << 2 | slot, row = Z * Ny + Y).  Same workspace size.
+TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey, int64_t nv, int Ny, float *uniq,
+                                        int32_t *rank, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
+                                        void *stream)
 {
-    if (!vpos || !uniq || !rank || !totals || !workspace || nv <= 0) return TOMO_E_ARG;
+    if (!vpos || !vkey || !uniq || !rank || !totals || !workspace || nv <= 0 || Ny <= 0) return TOMO_E_ARG;
     if (nv >= 0x7fffffffll) return TOMO_E_SIZE;
     UqLayout L = uq_layout(nv);
     if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
@@ -197,8 +208,8 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, int64_t nv, float *un
     size_t tb = L.temp_bytes;
     hipStream_t s = (hipStream_t)stream;
     unsigned blocks = (unsigned)ceil_div64(nv, 256);
-    hipLaunchKernelGGL(uq_keys_zy_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, kzy_a, idx_b);
-    if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 64, s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny, kzy_a, idx_b);
+    if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 48, s) != hipSuccess) return TOMO_E_LAUNCH;
     hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head, (u64 *)totals + 2);
     tb = L.temp_bytes;
     if (rocprim::inclusive_scan(temp, tb, head, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;

@@ -10,6 +10,9 @@
 // wave w of the field kernel (columns 32 + 256 w ...) is exactly segment w + 1.
 #define SEG_SHIFT 224
 
+// vertex / voxel key = (row << TOMO_KEY_ROW_SHIFT) | (X << 2) | slot, row = Z * Ny + Y (mc.hip, mesh.hip)
+#define TOMO_KEY_ROW_SHIFT 22
+
 typedef unsigned long long u64;
 typedef unsigned int u32;
 

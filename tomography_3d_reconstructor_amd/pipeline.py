@@ -15,6 +15,7 @@ import torch
 from . import _lib
 
 
+COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0}    # how often the one-sort unique path held / had to be redone
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
 
 
@@ -285,6 +286,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
                               int(z_offset), _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
     mesh = RawMesh(vkey, vpos, faces32[:nf])
     mesh._mc = (f, geo, vox_key, na, seg_act, seg_aoff, vox_voff, vox_flags)   # for first_touch_order (manifold=False)
+    mesh._ny = f.Ny       # rows of the field: the one-sort unique path derives the slice of a vertex from its key
     mesh._stats_fresh = True
     mesh._stats = stats   # stats[7] != 0 would mean a triangle corner without vertex (read with the unique totals)
     return mesh
@@ -327,8 +329,8 @@ def finalize_vertices(vpos: torch.Tensor, slice_depths, mm_per_pixel_y, mm_per_p
 def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     """_ensure_manifold_mesh (surface_extractor.py:115-126): unique vertex rows (lexicographic order) and
     remapped int64 faces without degenerate triangles.  mesh.vpos must already be finalised.
-    presorted: the rows are in marching-cubes order, so try the one-sort path first (tomo_mesh_unique_presorted)
-    and fall back to the two-sort path if it reports an order violation."""
+    presorted: the rows are in marching-cubes order with their keys (a RawMesh from marching_cubes), so try the
+    one-sort path first (tomo_mesh_unique_presorted) and fall back to the two-sort path if it reports a violation."""
     L = _lib.lib()
     dev = mesh.vpos.device
     nv, nf = mesh.vpos.shape[0], mesh.faces32.shape[0]
@@ -348,17 +350,26 @@ def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     if stats is None:
         stats, fresh = torch.zeros(16, dtype=torch.int64, device=dev), True
     mesh._stats_fresh = False
-    for attempt, fn in enumerate((L.tomo_mesh_unique_presorted, L.tomo_mesh_unique) if presorted else (L.tomo_mesh_unique,)):
+    ny = getattr(mesh, "_ny", None)
+    one_sort = presorted and mesh.vkey is not None and ny is not None
+    for attempt, fast in enumerate((True, False) if one_sort else (False,)):
         if attempt or not fresh:
             stats[8:12].zero_()
         totals = stats[8:12]
-        _lib.check(fn(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_unique")
+        if fast:
+            _lib.check(L.tomo_mesh_unique_presorted(_p(mesh.vpos), _p(mesh.vkey), nv, int(ny), _p(uniq), _p(rank), _p(totals),
+                                                    _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
+        else:
+            _lib.check(L.tomo_mesh_unique(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
+                       "tomo_mesh_unique")
         if nf > 0:
             _lib.check(L.tomo_mesh_faces(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _p(ws2), wsb2, _stream()),
                        "tomo_mesh_faces")
         host = stats.cpu()
         nbad = int(host[7])
         nu, nkeep, nviol = int(host[8]), int(host[9]), int(host[10])
+        if fast:
+            COUNTERS["unique_one_sort" if nviol == 0 else "unique_fallback"] += 1
         if nviol == 0:
             break
     if nbad:

@@ -31,4 +31,5 @@ for it in range(6):
         for k, s in enumerate(stages):
             acc[s].append(ev[k].elapsed_time(ev[k + 1]))
     del f, mesh, v, fa, vol
+print("unique path:", pipeline.COUNTERS)
 print(" | ".join("%s %.3f" % (s, float(np.mean(acc[s]))) for s in stages), "| total %.3f ms" % sum(float(np.mean(acc[s])) for s in stages))
