@@ -197,6 +197,11 @@ int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey
 int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);
 int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                     unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
+/* Speculative one-pass variant: faces_out[f] = rank[faces32[f]] for every face (int64), totals[1] = nf, and totals[3]
+ * (zeroed by the caller) += number of degenerate faces.  The result is final if and only if totals[3] stays 0; otherwise
+ * call tomo_mesh_faces. */
+int tomo_mesh_faces_direct(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
+                           unsigned long long *totals, void *stream);
 /* surface_extractor.py:128-149: out[0] = sum over faces of dot(v0, cross(v1,v2))/6 (float64
  * accumulation of float32 terms), out[1] = sum of 0.5*|cross(v1-v0, v2-v0)|.  out is zeroed by the
  * caller; tree reduction => parity with the reference's sequential sums is to 1e-6 rel, not bitwise. */

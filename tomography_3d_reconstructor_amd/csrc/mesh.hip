@@ -247,6 +247,35 @@ __global__ __launch_bounds__(256) void faces_compact_kernel(const int32_t *__res
     if (f == nf - 1) totals[1] = (u64)kscan[f];
 }
 
+// Speculative single pass: final ids straight to int64 at the face's own position, counting the degenerate faces.  If the
+// count is 0 -- no two vertices of a triangle merged, the usual case -- this IS the result (totals[1] = nf) and the
+// rank / scan / compact passes of tomo_mesh_faces are not needed; otherwise the caller runs tomo_mesh_faces.
+__global__ __launch_bounds__(256) void faces_direct_kernel(const int32_t *__restrict__ faces32, int64_t nf,
+                                                           const int32_t *__restrict__ rank, int64_t *__restrict__ faces_out,
+                                                           u64 *__restrict__ totals)
+{
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (f < nf) {
+        const int32_t a = rank[faces32[3 * f + 0]], b = rank[faces32[3 * f + 1]], c = rank[faces32[3 * f + 2]];
+        faces_out[3 * f + 0] = a; faces_out[3 * f + 1] = b; faces_out[3 * f + 2] = c;
+        bad = (a == b || b == c || a == c);
+    }
+    const u64 nbad = (u64)__popcll(__ballot(bad));
+    if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(&totals[3], (unsigned long long)nbad);
+    if (f == 0) totals[1] = (u64)nf;
+}
+
+TOMO_API int tomo_mesh_faces_direct(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
+                                    unsigned long long *totals, void *stream)
+{
+    if (!faces32 || !rank || !faces_out || !totals || nf <= 0) return TOMO_E_ARG;
+    if (nf >= 0x7fffffffll) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(faces_direct_kernel, dim3((unsigned)ceil_div64(nf, 256)), dim3(256), 0, (hipStream_t)stream, faces32, nf,
+                       rank, faces_out, (u64 *)totals);
+    return tomo_status();
+}
+
 struct FcLayout { size_t ids, keep, kscan, temp, temp_bytes, total; };
 
 static FcLayout fc_layout(int64_t nf)

@@ -15,7 +15,9 @@ import torch
 from . import _lib
 
 
-COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0}    # how often the one-sort unique path held / had to be redone
+# how often the speculative kernels of ensure_manifold_mesh held / had to be redone; a path that fails more often than
+# it holds in this process is no longer tried first
+COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0, "faces_direct": 0, "faces_fallback": 0}
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
 
 
@@ -352,26 +354,49 @@ def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     mesh._stats_fresh = False
     ny = getattr(mesh, "_ny", None)
     one_sort = presorted and mesh.vkey is not None and ny is not None
-    for attempt, fast in enumerate((True, False) if one_sort else (False,)):
-        if attempt or not fresh:
+    # Speculative fast paths first -- one-sort unique, one-pass face remap.  Each reports through a counter whether its
+    # result is exact; where it is not, the general kernel runs and the counters are downloaded again (ONE download per
+    # round, normally one round).
+    if COUNTERS["unique_fallback"] > COUNTERS["unique_one_sort"] + 2:
+        one_sort = False
+    do_unique = "one_sort" if one_sort else "general"          # None: uniq / rank are final
+    do_faces = "direct" if COUNTERS["faces_fallback"] <= COUNTERS["faces_direct"] + 2 else "compact"
+    nu = nkeep = nbad = 0
+    first = True
+    while True:
+        if not (first and fresh):
             stats[8:12].zero_()
+        first = False
         totals = stats[8:12]
-        if fast:
+        if do_unique == "one_sort":
             _lib.check(L.tomo_mesh_unique_presorted(_p(mesh.vpos), _p(mesh.vkey), nv, int(ny), _p(uniq), _p(rank), _p(totals),
                                                     _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
-        else:
+        elif do_unique == "general":
             _lib.check(L.tomo_mesh_unique(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
                        "tomo_mesh_unique")
-        if nf > 0:
+        if nf > 0 and do_faces == "direct":
+            _lib.check(L.tomo_mesh_faces_direct(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _stream()),
+                       "tomo_mesh_faces_direct")
+        elif nf > 0:
             _lib.check(L.tomo_mesh_faces(_p(mesh.faces32), nf, _p(rank), _p(faces), _p(totals), _p(ws2), wsb2, _stream()),
                        "tomo_mesh_faces")
         host = stats.cpu()
         nbad = int(host[7])
-        nu, nkeep, nviol = int(host[8]), int(host[9]), int(host[10])
-        if fast:
+        if do_unique is not None:
+            nu = int(host[8])
+        nkeep, nviol, ndegen = int(host[9]), int(host[10]), int(host[11])
+        if do_unique == "one_sort":
             COUNTERS["unique_one_sort" if nviol == 0 else "unique_fallback"] += 1
-        if nviol == 0:
-            break
+            if nviol:
+                do_unique = "general"                            # the order check failed: sort properly, remap again
+                continue
+        do_unique = None
+        if nf > 0 and do_faces == "direct":
+            COUNTERS["faces_fallback" if ndegen else "faces_direct"] += 1
+            if ndegen:
+                do_faces = "compact"                             # some triangles collapsed: drop them, keep the order
+                continue
+        break
     if nbad:
         raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % nbad)
     verts = uniq[:nu]
