@@ -195,6 +195,10 @@ int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey
                                int32_t *rank, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
                                void *stream);
 int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);
+/* out[i] = index of query row i in the sorted duplicate-free row list uniq (nu x 3), -1 (and *missing += 1, a device
+ * counter the caller zeroes) if it is not there.  Used by the Z-slab job for the shared-plane vertices. */
+int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t nq, int32_t *out,
+                     unsigned long long *missing, void *stream);
 int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                     unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* Speculative one-pass variant: faces_out[f] = rank[faces32[f]] for every face (int64), totals[1] = nf, and totals[3]

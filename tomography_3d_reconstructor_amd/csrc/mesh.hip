@@ -218,6 +218,40 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     return tomo_status();
 }
 
+// ------------------------------------------------------------------------------------------ lookup
+// Index of every query row in a lexicographically sorted, duplicate-free (U,3) row list (binary search); a row that is
+// not there gets -1 and is counted in *missing.  The Z-slab job uses it to number the few thousand shared-plane vertices
+// a rank receives from below against its own unique list instead of sorting them in.
+__global__ __launch_bounds__(256) void rows_lookup_kernel(const float *__restrict__ uniq, int64_t nu,
+                                                          const float *__restrict__ query, int64_t nq,
+                                                          int32_t *__restrict__ out, u64 *__restrict__ missing)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float qz = query[3 * i], qy = query[3 * i + 1], qx = query[3 * i + 2];
+    int64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const float *m = uniq + 3 * mid;
+        const bool less = m[0] < qz || (m[0] == qz && (m[1] < qy || (m[1] == qy && m[2] < qx)));
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    const bool found = lo < nu && uniq[3 * lo] == qz && uniq[3 * lo + 1] == qy && uniq[3 * lo + 2] == qx;
+    out[i] = found ? (int32_t)lo : -1;
+    if (!found) atomicAdd(missing, 1ull);
+}
+
+TOMO_API int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t nq, int32_t *out,
+                              unsigned long long *missing, void *stream)
+{
+    if (nq < 0 || nu < 0 || (nq > 0 && (!query || !out || !missing)) || (nu > 0 && !uniq)) return TOMO_E_ARG;
+    if (nq == 0) return TOMO_OK;
+    if (nu >= 0x7fffffffll) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(rows_lookup_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, (hipStream_t)stream, uniq, nu,
+                       query, nq, out, (u64 *)missing);
+    return tomo_status();
+}
+
 // ------------------------------------------------------------------------------------------ faces
 // provisional vertex ids (int32, from mc_emit) -> final ids through `rank`, drop triangles with fewer than
 // three distinct indices (order kept), widen to int64 like np.unique's inverse.

@@ -404,6 +404,74 @@ def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     return verts, faces
 
 
+def unique_rows(vpos: torch.Tensor, vkey: torch.Tensor = None, ny: int = None):
+    """np.unique(rows, axis=0, return_inverse=True) of finalised vertex rows -> (uniq (U,3), rank (V,) int32).  With the
+    marching-cubes keys of the rows (and the field's row count) the one-sort path is tried first."""
+    L = _lib.lib()
+    dev = vpos.device
+    nv = vpos.shape[0]
+    vpos = vpos.contiguous()
+    uniq = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    rank = torch.empty(nv, dtype=torch.int32, device=dev)
+    if nv == 0:
+        return uniq, rank
+    wsb = L.tomo_mesh_unique_workspace_bytes(nv)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    fast = vkey is not None and ny is not None and COUNTERS["unique_fallback"] <= COUNTERS["unique_one_sort"] + 2
+    while True:
+        totals = torch.zeros(4, dtype=torch.int64, device=dev)
+        if fast:
+            _lib.check(L.tomo_mesh_unique_presorted(_p(vpos), _p(vkey.contiguous()), nv, int(ny), _p(uniq), _p(rank), _p(totals),
+                                                    _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
+        else:
+            _lib.check(L.tomo_mesh_unique(_p(vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_unique")
+        host = totals.cpu()
+        if fast:
+            COUNTERS["unique_one_sort" if int(host[2]) == 0 else "unique_fallback"] += 1
+            if int(host[2]):
+                fast = False
+                continue
+        return uniq[: int(host[0])], rank
+
+
+def lookup_rows(uniq: torch.Tensor, query: torch.Tensor):
+    """Index of every query row in the sorted unique row list -> (idx (Q,) int32, number of rows not found)."""
+    dev = uniq.device
+    nq = query.shape[0]
+    out = torch.empty(nq, dtype=torch.int32, device=dev)
+    if nq == 0:
+        return out, 0
+    miss = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().tomo_mesh_lookup(_p(uniq.contiguous()), uniq.shape[0], _p(query.contiguous()), nq, _p(out), _p(miss),
+                                           _stream()), "tomo_mesh_lookup")
+    return out, int(miss.item())
+
+
+def remap_faces(faces32: torch.Tensor, gid32: torch.Tensor):
+    """faces (F,3) int64 = gid32[faces32] without the degenerate triangles, order kept (the face half of
+    _ensure_manifold_mesh for an arbitrary provisional -> final index map)."""
+    L = _lib.lib()
+    dev = faces32.device
+    nf = faces32.shape[0]
+    if nf == 0:
+        return torch.zeros((0, 3), dtype=torch.int64, device=dev)
+    faces = torch.empty((nf, 3), dtype=torch.int64, device=dev)
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    faces32, gid32 = faces32.contiguous(), gid32.contiguous()
+    direct = COUNTERS["faces_fallback"] <= COUNTERS["faces_direct"] + 2
+    if direct:
+        _lib.check(L.tomo_mesh_faces_direct(_p(faces32), nf, _p(gid32), _p(faces), _p(totals), _stream()), "tomo_mesh_faces_direct")
+        host = totals.cpu()
+        COUNTERS["faces_fallback" if int(host[3]) else "faces_direct"] += 1
+        if int(host[3]) == 0:
+            return faces
+        totals.zero_()
+    wsb = L.tomo_mesh_faces_workspace_bytes(nf)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(L.tomo_mesh_faces(_p(faces32), nf, _p(gid32), _p(faces), _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_faces")
+    return faces[: int(totals[1].item())]
+
+
 def first_touch_order(mesh: RawMesh):
     """Renumber a RawMesh the way skimage numbers vertices (order of first touch in the serial cell scan).
     Returns (vpos (V,3) float32, faces (F,3) int32): what measure.marching_cubes returns to the reference."""

@@ -210,6 +210,18 @@ class HipEngine:
         return uniq[: int(totals[0].item())], rank
 
 
+    # optional fast paths (engines without them -- the CPU oracle engine of the tests -- use unique() and torch ops)
+    def unique_mc(self, vpos, vkey, ny):
+        """unique() for rows in marching-cubes order with their keys: one-sort path with automatic fallback."""
+        return pipeline.unique_rows(vpos, vkey, ny)
+
+    def lookup(self, uniq, query):
+        return pipeline.lookup_rows(uniq, query)
+
+    def remap_faces(self, faces32, gid32):
+        return pipeline.remap_faces(faces32, gid32)
+
+
 # ----------------------------------------------------------------------------- the job
 def slab_range(gz, rank, world):
     base, rem = divmod(gz, world)
@@ -303,28 +315,36 @@ class SlabJob:
         Za = 0 if first else self.z0 + 1            # global padded index of the first owned slice
         mesh = e.marching_cubes(f, Za)
         dev = mask.device
+        vkey = ny = None
         if mesh is None:
             vpos = torch.zeros((0, 3), dtype=torch.float32, device=dev)
             faces32 = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         else:
             vpos, faces32 = mesh.vpos, mesh.faces32
+            vkey, ny = getattr(mesh, "vkey", None), getattr(mesh, "_ny", None)
             e.finalize_vertices(vpos, slice_depths, mm_y, mm_x)
-        return self._global_numbering(vpos, faces32, slice_depths, dev)
+        return self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
 
     # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
-    def _global_numbering(self, vpos, faces32, slice_depths, dev):
+    def _global_numbering(self, vpos, faces32, slice_depths, dev, vkey=None, ny=None):
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
         nv = vpos.shape[0]
+        fast = vkey is not None and ny is not None and hasattr(e, "unique_mc")     # rows in marching-cubes order, with keys
         if self.world == 1:
-            uniq, rank = (e.unique(vpos) if nv else (vpos, torch.zeros(0, dtype=torch.int32, device=dev)))
-            faces = self._faces(faces32, rank.to(torch.int64))
+            if not nv:
+                uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
+            else:
+                uniq, rank = e.unique_mc(vpos, vkey, ny) if fast else e.unique(vpos)
             self.vertex_offset, self.n_vertices_global = 0, uniq.shape[0]
-            return uniq, faces
+            return uniq, self._faces(faces32, rank.to(torch.int64))
         # mapped z of the shared plane Zb = z1 + 1 (padded) through the same finalisation arithmetic
         if not last:
-            zb = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
-            zb = float(e.finalize_vertices(zb, slice_depths, 1.0, 1.0)[0, 0].item())
+            zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
+            if getattr(self, "_zb_key", None) != zkey:             # depends on the depth table only: once per table
+                zt = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
+                self._zb, self._zb_key = float(e.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
+            zb = self._zb
             top = (vpos[:, 0] == zb) if nv else torch.zeros(0, dtype=torch.bool, device=dev)
         else:
             top = torch.zeros(nv, dtype=torch.bool, device=dev)
@@ -337,11 +357,23 @@ class SlabJob:
         from_prev, _ = c.exchange(None, vpos[top_idx].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
         own = vpos[keep_idx]
         n_own = own.shape[0]
-        allv = torch.cat([own, from_prev.reshape(-1, 3)], 0) if from_prev is not None else own
-        if allv.shape[0]:
-            uniq, rank = e.unique(allv.contiguous())
-        else:
-            uniq, rank = allv, torch.zeros(0, dtype=torch.int32, device=dev)
+        prev_rows = from_prev.reshape(-1, 3) if from_prev is not None else own[:0]
+        uniq = rank = None
+        if fast and n_own:
+            # the rank's own vertices through the one-sort path; the few shared-plane vertices from below are copies of
+            # vertices this rank has itself, so they are looked up in its unique list instead of being sorted in
+            uniq, rank_own = e.unique_mc(own.contiguous(), vkey[keep_idx].contiguous(), ny)
+            idx_prev, missing = e.lookup(uniq, prev_rows.contiguous())
+            if missing == 0:
+                rank = torch.cat([rank_own, idx_prev], 0)
+            else:
+                uniq = None                                       # a vertex from below that is new here: sort everything
+        if uniq is None:
+            allv = torch.cat([own, prev_rows], 0)
+            if allv.shape[0]:
+                uniq, rank = e.unique(allv.contiguous())
+            else:
+                uniq, rank = allv, torch.zeros(0, dtype=torch.int32, device=dev)
         # indices of the lower neighbour's top-plane vertices go back down
         _, ids_next = c.exchange(rank[n_own:].contiguous(), None, torch.int32, recv_shape_next=(n_top,))
         counts = c.all_gather(torch.tensor([uniq.shape[0]], dtype=torch.int64, device=dev))
@@ -354,10 +386,11 @@ class SlabJob:
             gid[top_idx] = ids_next.to(torch.int64) + int(offs[self.rank + 1])
         return uniq, self._faces(faces32, gid)
 
-    @staticmethod
-    def _faces(faces32, gid):
+    def _faces(self, faces32, gid):
         if faces32.shape[0] == 0:
             return torch.zeros((0, 3), dtype=torch.int64, device=faces32.device)
+        if hasattr(self.eng, "remap_faces") and self.n_vertices_global < 2 ** 31:
+            return self.eng.remap_faces(faces32, gid.to(torch.int32))
         f = gid[faces32.to(torch.int64)]
         keep = (f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])
         return f[keep]

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Cost of the Z-slab (multi-GPU) path per rank, rehearsed on ONE GPU: `world` rank threads share the device and talk
+through the in-process communicator, each owning NZ slices of an NY x NX ellipsoid stack.  Prints the wall time of a
+step (all ranks' GPU work serialised on the one device) next to `world` x the single-GPU pipeline on one slab's worth.
+usage: slabbench.py [world] [NZ_per_rank] [NY] [NX]"""
+import os, sys, threading, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomography_3d_reconstructor_amd import pipeline, slab  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+nzr = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+ny = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+nx = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+dev = torch.device("cuda:0")
+gz = nzr * world
+depths = np.full(gz, 1.0)
+steps = 6
+times = []
+bar = threading.Barrier(world)
+
+
+def target(c):
+    job = slab.SlabJob(gz, ny, nx, c)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
+        for it in range(steps + 2):
+            bar.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            v, f = job.run(mask, depths, 1.0, 1.0)
+            torch.cuda.current_stream().synchronize()
+            bar.wait()
+            if c.rank == 0 and it >= 2:
+                times.append(time.perf_counter() - t0)
+
+
+ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
+[t.start() for t in ts]
+[t.join(600) for t in ts]
+slab_ms = float(np.mean(times)) * 1e3
+# the single-GPU pipeline on a volume of one slab's size, for scale
+m1 = pipeline.ellipsoid_mask(nzr, ny, nx, dev).view(torch.uint8)
+d1 = np.full(nzr, 1.0)
+for it in range(steps + 2):
+    if it == 2:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    vol = pipeline.smooth(pipeline.close_ends(pipeline.pack(m1), inplace=True), 3, True)
+    pipeline.extract_surface(vol, d1, 1.0, 1.0)
+torch.cuda.synchronize()
+one_ms = (time.perf_counter() - t0) / steps * 1e3
+print("world %d x (%d, %d, %d): slab step %.2f ms on one shared GPU = %.2f ms per rank; single pipeline on one slab-sized volume %.2f ms"
+      % (world, nzr, ny, nx, slab_ms, slab_ms / world, one_ms))
