@@ -154,3 +154,25 @@ def test_orchestrator_sequence_end_to_end(dev, tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         assert OBJExporter().export_to_obj(a[5], a[6], pth)
     assert open(pth).read() == O.obj_text(b[5], b[6])
+
+
+def test_create_voxel_data_input_forms(dev):
+    """Boundary behaviour of create_voxel_data for the input forms the reference accepts through np.stack: a ragged list
+    raises ValueError like np.stack does, uint8 0/255 masks count as `!= 0`, a list of views of one array (what the
+    loader hands out) and a list of separate arrays give the same volume."""
+    rng = np.random.default_rng(8)
+    v = rng.random((7, 40, 70)) < 0.4
+    sides = (2, 3, 2)
+    ref = O.VoxelProcessor()
+    with contextlib.redirect_stdout(io.StringIO()):
+        exp = ref.create_voxel_data(list(v), True, *sides)
+        a = VoxelProcessor().create_voxel_data([m.copy() for m in v], True, *sides)
+        b = VoxelProcessor().create_voxel_data([v[i] for i in range(len(v))], True, *sides)            # views of one base
+        c = VoxelProcessor().create_voxel_data([(m * 255).astype(np.uint8) for m in v], True, *sides)   # grey-level masks
+        d = VoxelProcessor().create_voxel_data([m.copy() for m in v], False, *sides)
+    assert np.array_equal(a, exp) and np.array_equal(b, exp) and np.array_equal(c, exp)
+    assert d.dtype == np.bool_ and np.array_equal(d, v) and not np.shares_memory(d, v)
+    with pytest.raises(ValueError):
+        VoxelProcessor().create_voxel_data([v[0], v[1][:-1]], True, 0, 2, 0)
+    with pytest.raises(ValueError, match="Load masks first, hmm."):
+        VoxelProcessor().create_voxel_data([], True)
