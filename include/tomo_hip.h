@@ -134,20 +134,19 @@ int tomo_field_signs(const float *field, int Nz, int Ny, int Nx, int64_t pitch, 
  *    empty segments stay unwritten and are never read).  No float is read. */
 int tomo_mc_classify(const unsigned long long *signs, const uint8_t *gcls, int Nz, int Ny, int Nx, int xorg,
                      unsigned long long *seg_act, uint32_t *seg_cnt, void *stream);
-/* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of seg_cnt, active_segs uint32[nseg] = indices
- * of the non-empty segments in order, totals (device uint64[4]) = {active voxels, 0, non-empty segments, 0}. */
-int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff, uint32_t *active_segs,
-                          unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
-/* Exclusive scan of packed counts (low 16 bits -> off_a, high 16 bits -> off_b; both uint32[n + 1], off_b may
- * be NULL), list of the indices of the non-zero entries (nz_ids uint32[n], may be NULL) and
- * totals (device uint64[4]) = {sum low, sum high, number of non-zero entries, 0}.
- * workspace: tomo_mc_scan_workspace_bytes(n) bytes. */
+/* Segment-level scan: seg_aoff uint32[nseg + 1] = exclusive scan of seg_cnt, totals (device uint64[4]) =
+ * {active voxels, 0, 0, 0}.  workspace: tomo_mc_scan_workspace_bytes(nseg) bytes. */
+int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff, unsigned long long *totals,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+/* Exclusive scan of packed counts (low 16 bits -> off_a, high 16 bits -> off_b; both uint32[n + 1]; with off_b = NULL
+ * the counts are plain numbers and off_a their exclusive scan), totals (device uint64[4]) = {sum low, sum high, 0, 0}.
+ * nz_ids must be NULL (kept for the call shape).  workspace: tomo_mc_scan_workspace_bytes(n) bytes. */
 int64_t tomo_mc_scan_workspace_bytes(int64_t n);
 int tomo_mc_scan(const uint32_t *counts, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
                  unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* 2. list: vox_key[na] = keys of the active voxels, ascending (cell scan order), from seg_act. */
 int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
-                 const uint32_t *active_segs, int64_t n_active_segs, unsigned long long *vox_key, void *stream);
+                 unsigned long long *vox_key, void *stream);
 /* 3. eval: one MC33 evaluation per active voxel: vox_counts[na] = ntri << 16 | nvert,
  * vox_flags[na] = bit0/1/2 edge vertices, bit3 centre vertex. */
 int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,

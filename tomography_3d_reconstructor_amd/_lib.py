@@ -53,10 +53,10 @@ SIGNATURES = {
     "tomo_sign_buffer_words": (_c_i64, [_c_i, _c_i, _c_i, _c_i]),
     "tomo_field_signs": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_i, _c_i, _c_p, _c_p, _c_p]),
     "tomo_mc_classify": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
-    "tomo_mc_scan_segments": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "tomo_mc_scan_segments": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mc_scan_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mc_scan": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
-    "tomo_mc_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "tomo_mc_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p]),
     "tomo_mc_eval": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "tomo_mc_emit": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p,
                             _c_p, _c_p, _c_p, _c_p]),

@@ -19,7 +19,10 @@
 //     cell scan order, LUT order inside a cell; triangle corners are resolved to vertex indices by a
 //     search in the active list restricted to the owner voxel's segment (a handful of entries).
 // No atomics decide any position: output is deterministic.
+#include <cstring>
+#include <cstdlib>
 #include "tomo_common.h"
+#include <rocprim/rocprim.hpp>
 
 #define MC_LUT_QUAL __device__ const
 #define MC_FN __device__ static inline
@@ -215,172 +218,93 @@ TOMO_API int tomo_mc_classify(const unsigned long long *signs, const uint8_t *gc
 }
 
 // ------------------------------------------------------------------------------------------ scan
-// Exclusive scan of packed counts (hi 16 bits: b, lo 16 bits: a) plus the compact list of non-zero
-// entries: block sums -> one-block scan -> apply.  Used twice: over segments (a = active voxels) and
-// over active voxels (a = vertices, b = triangles).
-#define SCAN_ITEMS 16
-#define SCAN_BLOCK (256 * SCAN_ITEMS)
-
-// count of entry i: either a packed uint32 or, for the segment level, the popcount of a 4 x uint64 ballot record
-__device__ static inline u32 scan_load(const u32 *__restrict__ counts, const u64 *__restrict__ act, int64_t i)
-{
-    if (act) {
-        const ulonglong2 *q = (const ulonglong2 *)(act + 4 * i);
-        ulonglong2 a = q[0], b = q[1];
-        return (u32)(__popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y));
+// Exclusive scans of packed counts (low 16 bits: a, high 16 bits: b) with rocPRIM's single-pass (decoupled look-back)
+// scan: input through a transform iterator that unpacks a count into an (a, b) pair, output through a zip iterator
+// straight into the two offset arrays.  Used over segments (a = active voxels) and over active voxels (a = vertices,
+// b = triangles).  off[0] = 0 and the totals are written by a one-thread kernel.
+struct ScanPair { u32 a, b; };
+struct ScanUnpack {
+    __host__ __device__ rocprim::tuple<u32, u32> operator()(u32 c) const { return rocprim::make_tuple(c & 0xffffu, c >> 16); }
+};
+struct ScanAdd {
+    __host__ __device__ rocprim::tuple<u32, u32> operator()(const rocprim::tuple<u32, u32> &x,
+                                                            const rocprim::tuple<u32, u32> &y) const
+    {
+        return rocprim::make_tuple(rocprim::get<0>(x) + rocprim::get<0>(y), rocprim::get<1>(x) + rocprim::get<1>(y));
     }
-    return counts[i];
-}
+};
 
-__global__ __launch_bounds__(256) void scan_reduce_kernel(const u32 *__restrict__ counts, const u64 *__restrict__ act,
-                                                          int64_t n, u64 *__restrict__ bsum)
+__global__ void scan_finish_kernel(u32 *__restrict__ off_a, u32 *__restrict__ off_b, int64_t n, u64 *__restrict__ totals)
 {
-    __shared__ u64 sv[4], sf[4], sa[4];
-    int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    u64 v = 0, f = 0, a = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        int64_t i = base + k;
-        u32 c = i < n ? scan_load(counts, act, i) : 0u;
-        v += c & 0xffffu; f += c >> 16; a += c != 0u;
-    }
-    v = wave_sum64(v); f = wave_sum64(f); a = wave_sum64(a);
-    int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sv[w] = v; sf[w] = f; sa[w] = a; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bsum[3 * (int64_t)blockIdx.x + 0] = sv[0] + sv[1] + sv[2] + sv[3];
-        bsum[3 * (int64_t)blockIdx.x + 1] = sf[0] + sf[1] + sf[2] + sf[3];
-        bsum[3 * (int64_t)blockIdx.x + 2] = sa[0] + sa[1] + sa[2] + sa[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        off_a[0] = 0u;
+        if (off_b) off_b[0] = 0u;
+        totals[0] = off_a[n];
+        totals[1] = off_b ? off_b[n] : 0ull;
+        totals[2] = 0ull;
+        totals[3] = 0ull;
     }
 }
 
-// single block: exclusive scan of the block sums in place, totals out
-__global__ __launch_bounds__(256) void scan_blocks_kernel(u64 *__restrict__ bsum, int64_t nblocks, u64 *__restrict__ totals)
+static size_t scan_temp_bytes(int64_t n)
 {
-    __shared__ u64 carry[3];
-    __shared__ u64 wsum[4][3];
-    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t start = 0; start < nblocks; start += 256) {
-        int64_t i = start + threadIdx.x;
-        u64 x[3], inc[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) x[c] = i < nblocks ? bsum[3 * i + c] : 0ull;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            u64 v = x[c];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                u64 o = __shfl_up(v, d, 64);
-                if (lane >= d) v += o;
-            }
-            inc[c] = v;
-            if (lane == 63) wsum[w][c] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            u64 off = carry[c];
-            for (int j = 0; j < w; j++) off += wsum[j][c];
-            if (i < nblocks) bsum[3 * i + c] = off + inc[c] - x[c];
-        }
-        __syncthreads();
-        if (threadIdx.x < 3)
-            carry[threadIdx.x] += wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) totals[threadIdx.x] = carry[threadIdx.x];
-    if (threadIdx.x == 3) totals[3] = 0;
+    size_t t1 = 0, t2 = 0;
+    size_t m = (size_t)(n > 0 ? n : 1);
+    (void)rocprim::inclusive_scan(nullptr, t1, (u32 *)nullptr, (u32 *)nullptr, m, rocprim::plus<u32>(), (hipStream_t)0);
+    auto in = rocprim::make_transform_iterator((const u32 *)nullptr, ScanUnpack());
+    auto out = rocprim::make_zip_iterator(rocprim::make_tuple((u32 *)nullptr, (u32 *)nullptr));
+    (void)rocprim::inclusive_scan(nullptr, t2, in, out, m, ScanAdd(), (hipStream_t)0);
+    return t1 > t2 ? t1 : t2;
 }
 
-__global__ __launch_bounds__(256) void scan_apply_kernel(const u32 *__restrict__ counts, const u64 *__restrict__ act,
-                                                         int64_t n, const u64 *__restrict__ bsum, u32 *__restrict__ off_a,
-                                                         u32 *__restrict__ off_b, u32 *__restrict__ nz_ids)
-{
-    __shared__ u64 wv[4], wf[4], wa[4];
-    int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    u32 c[SCAN_ITEMS];
-    u64 v = 0, f = 0, a = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        int64_t i = base + k;
-        c[k] = i < n ? scan_load(counts, act, i) : 0u;
-        v += c[k] & 0xffffu; f += c[k] >> 16; a += c[k] != 0u;
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u64 iv = v, jf = f, ia = a;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 o1 = __shfl_up(iv, d, 64), o2 = __shfl_up(jf, d, 64), o3 = __shfl_up(ia, d, 64);
-        if (lane >= d) { iv += o1; jf += o2; ia += o3; }
-    }
-    if (lane == 63) { wv[w] = iv; wf[w] = jf; wa[w] = ia; }
-    __syncthreads();
-    u64 ov = bsum[3 * (int64_t)blockIdx.x + 0] + iv - v, of = bsum[3 * (int64_t)blockIdx.x + 1] + jf - f,
-        oa = bsum[3 * (int64_t)blockIdx.x + 2] + ia - a;
-    for (int j = 0; j < w; j++) { ov += wv[j]; of += wf[j]; oa += wa[j]; }
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        int64_t i = base + k;
-        if (i < n) {
-            off_a[i] = (u32)ov;
-            if (off_b) off_b[i] = (u32)of;
-            if (nz_ids && c[k]) nz_ids[oa] = (u32)i;
-        }
-        ov += c[k] & 0xffffu; of += c[k] >> 16; oa += c[k] != 0u;
-    }
-    if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) {   // end sentinels
-        off_a[n] = (u32)ov;
-        if (off_b) off_b[n] = (u32)of;
-    }
-}
+TOMO_API int64_t tomo_mc_scan_workspace_bytes(int64_t n) { return (int64_t)scan_temp_bytes(n) + 256; }
 
-TOMO_API int64_t tomo_mc_scan_workspace_bytes(int64_t n)
+// off_a[i] = sum of the low halves of counts[0 .. i), off_b likewise for the high halves (off_b may be NULL: then the
+// counts are plain numbers < 2^32 and off_a their exclusive scan); both have n + 1 entries.
+static int scan_launch(const u32 *counts, int64_t n, uint32_t *off_a, uint32_t *off_b, unsigned long long *totals,
+                       void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return (ceil_div64(n > 0 ? n : 1, SCAN_BLOCK) * 3 + 8) * (int64_t)sizeof(u64);
-}
-
-static int scan_launch(const u32 *counts, const u64 *act, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
-                       unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
-{
-    if ((!counts && !act) || !off_a || !totals || !workspace || n <= 0) return TOMO_E_ARG;
+    if (!counts || !off_a || !totals || !workspace || n <= 0) return TOMO_E_ARG;
     if (n >= 0xffffffffll) return TOMO_E_SIZE;
-    if (workspace_bytes < tomo_mc_scan_workspace_bytes(n)) return TOMO_E_WORKSPACE;
-    int64_t nblocks = ceil_div64(n, SCAN_BLOCK);
-    u64 *bsum = (u64 *)workspace;
+    size_t tb = scan_temp_bytes(n);
+    if (workspace_bytes < (int64_t)tb) return TOMO_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, counts, act, n, bsum);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, bsum, nblocks, (u64 *)totals);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, counts, act, n, (const u64 *)bsum,
-                       off_a, off_b, nz_ids);
+    hipError_t rc;
+    if (off_b) {
+        auto in = rocprim::make_transform_iterator(counts, ScanUnpack());
+        auto out = rocprim::make_zip_iterator(rocprim::make_tuple(off_a + 1, off_b + 1));
+        rc = rocprim::inclusive_scan(workspace, tb, in, out, (size_t)n, ScanAdd(), s);
+    } else {
+        rc = rocprim::inclusive_scan(workspace, tb, counts, off_a + 1, (size_t)n, rocprim::plus<u32>(), s);
+    }
+    if (rc != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(1), dim3(64), 0, s, off_a, off_b, n, (u64 *)totals);
     return tomo_status();
 }
 
 TOMO_API int tomo_mc_scan(const uint32_t *counts, int64_t n, uint32_t *off_a, uint32_t *off_b, uint32_t *nz_ids,
                           unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return scan_launch(counts, nullptr, n, off_a, off_b, nz_ids, totals, workspace, workspace_bytes, stream);
+    if (nz_ids) return TOMO_E_ARG;            // the list of non-zero entries is no longer produced (ABI 2)
+    return scan_launch(counts, n, off_a, off_b, totals, workspace, workspace_bytes, stream);
 }
 
-TOMO_API int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff,
-                                   uint32_t *active_segs, unsigned long long *totals, void *workspace,
-                                   int64_t workspace_bytes, void *stream)
+TOMO_API int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32_t *seg_aoff, unsigned long long *totals,
+                                   void *workspace, int64_t workspace_bytes, void *stream)
 {
-    return scan_launch(seg_cnt, nullptr, nseg, seg_aoff, nullptr, active_segs, totals, workspace, workspace_bytes, stream);
+    return scan_launch(seg_cnt, nseg, seg_aoff, nullptr, totals, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------ pass 2
-// one LANE per active segment (consecutive lanes write consecutive ranges of vox_key): expand the four
+// one LANE per segment; the non-empty ones (consecutive lanes write consecutive ranges of vox_key) expand the four
 // ballots written by pass 1 into voxel keys, in x order
 __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
-                                                      const u64 *__restrict__ seg_act, const u32 *__restrict__ active_segs,
-                                                      int64_t n_active_segs, u64 *__restrict__ vox_key)
+                                                      const u64 *__restrict__ seg_act, int64_t nseg,
+                                                      u64 *__restrict__ vox_key)
 {
-    int64_t ai = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ai >= n_active_segs) return;
-    int64_t seg = active_segs[ai];
+    int64_t seg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= nseg) return;
+    if (seg_aoff[seg + 1] == seg_aoff[seg]) return;             // empty: its ballot record was never written
     int s = (int)(seg % g.segs_per_row);
     int64_t row = seg / g.segs_per_row;
     const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
@@ -401,16 +325,16 @@ __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 
 }
 
 TOMO_API int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
-                          const uint32_t *active_segs, int64_t n_active_segs, unsigned long long *vox_key, void *stream)
+                          unsigned long long *vox_key, void *stream)
 {
-    if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_aoff || !seg_act || !active_segs || !vox_key) return TOMO_E_ARG;
-    if (n_active_segs <= 0) return TOMO_OK;
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_aoff || !seg_act || !vox_key) return TOMO_E_ARG;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
-    int64_t blocks = ceil_div64(n_active_segs, 256);
+    const int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row;
+    int64_t blocks = ceil_div64(nseg, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_list_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, seg_aoff,
-                       (const u64 *)seg_act, active_segs, n_active_segs, (u64 *)vox_key);
+                       (const u64 *)seg_act, nseg, (u64 *)vox_key);
     return tomo_status();
 }
 

@@ -248,23 +248,20 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)       # active voxels of every segment
     _lib.check(L.tomo_mc_classify(_p(f.signs), _p(f.gcls), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
     seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-    active_segs = torch.empty(nseg, dtype=torch.int32, device=dev)
     stats = torch.zeros(16, dtype=torch.int64, device=dev)   # [0:4] segment scan, [4:8] voxel scan + emit errors, [8:12] unique
     totals = stats[:8]
     wsb = L.tomo_mc_scan_workspace_bytes(nseg)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mc_scan_segments(_p(seg_cnt), nseg, _p(seg_aoff), _p(active_segs), _p(totals), _p(ws), wsb, st),
-               "tomo_mc_scan_segments")
-    na, _, nas, _ = [int(x) for x in totals[:4].cpu()]
+    _lib.check(L.tomo_mc_scan_segments(_p(seg_cnt), nseg, _p(seg_aoff), _p(totals), _p(ws), wsb, st), "tomo_mc_scan_segments")
+    na = int(totals[0].item())
     if na == 0:
         return None
     if na >= 2 ** 31:
         raise _lib.TomoError("surface too large for 32-bit indices")
     # pass 2-3: compact voxel list, one MC33 evaluation per active voxel, scan of the counts
     vox_key = torch.empty(na, dtype=torch.int64, device=dev)
-    _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(active_segs), nas, _p(vox_key), st),
-               "tomo_mc_list")
-    del active_segs, seg_cnt
+    _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(vox_key), st), "tomo_mc_list")
+    del seg_cnt
     vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
     vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
     _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")
@@ -275,7 +272,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
     _lib.check(L.tomo_mc_scan(_p(vox_counts), na, _p(vox_voff), _p(vox_foff), None, _p(tot2), _p(ws2), wsb2, st),
                "tomo_mc_scan")
-    nv, nf, _, _ = [int(x) for x in tot2.cpu()]
+    nv, nf = [int(x) for x in tot2[:2].cpu()]
     if nv == 0:
         return None
     if nv >= 2 ** 31 or nf >= 2 ** 31:
