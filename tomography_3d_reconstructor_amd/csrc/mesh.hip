@@ -106,6 +106,47 @@ __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__
     head[i] = h;
 }
 
+// head flag of sorted position i as a function object: lets the scan read the flags through a transform iterator
+// instead of an array (one kernel and 14 MB of traffic less per 3.5 M vertices)
+struct UqHead {
+    const float *vpos;
+    const u32 *idx;
+    __device__ u32 operator()(u32 i) const
+    {
+        if (i == 0) return 1u;
+        const float *a = vpos + 3 * (int64_t)idx[i], *b = vpos + 3 * (int64_t)idx[i - 1];
+        return (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
+    }
+};
+
+// scatter of the one-sort path: recomputes the head flag (same two rows the order check needs anyway), counts the places
+// where the sorted result descends lexicographically, writes uniq / rank
+__global__ __launch_bounds__(256) void uq_scatter_check_kernel(const float *__restrict__ vpos, int64_t nv,
+                                                               const u32 *__restrict__ idx, const u32 *__restrict__ hscan,
+                                                               float *__restrict__ uniq, int32_t *__restrict__ rank,
+                                                               u64 *__restrict__ totals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const u32 src = idx[i];
+    const float *a = vpos + 3 * (int64_t)src;
+    const float a0 = a[0], a1 = a[1], a2 = a[2];
+    bool head = true;
+    if (i > 0) {
+        const float *b = vpos + 3 * (int64_t)idx[i - 1];
+        const float b0 = b[0], b1 = b[1], b2 = b[2];
+        head = (a0 != b0 || a1 != b1 || a2 != b2);
+        if (a0 < b0 || (a0 == b0 && (a1 < b1 || (a1 == b1 && a2 < b2)))) atomicAdd(&totals[2], 1ull);
+    }
+    const u32 u = hscan[i] - 1u;
+    rank[src] = (int32_t)u;
+    if (head) {
+        float *q = uniq + 3 * (int64_t)u;
+        q[0] = a0; q[1] = a1; q[2] = a2;
+    }
+    if (i == nv - 1) totals[0] = (u64)hscan[i];
+}
+
 __global__ __launch_bounds__(256) void uq_scatter_kernel(const float *__restrict__ vpos, int64_t nv,
                                                          const u32 *__restrict__ idx, const u32 *__restrict__ head,
                                                          const u32 *__restrict__ hscan, float *__restrict__ uniq,
@@ -145,8 +186,12 @@ static UqLayout uq_layout(int64_t nv)
     (void)rocprim::radix_sort_pairs(nullptr, t2, (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, n, 0, 64,
                               (hipStream_t)0);
     (void)rocprim::inclusive_scan(nullptr, t3, (u32 *)nullptr, (u32 *)nullptr, n, rocprim::plus<u32>(), (hipStream_t)0);
+    size_t t4 = 0;
+    auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{nullptr, nullptr});
+    (void)rocprim::inclusive_scan(nullptr, t4, heads, (u32 *)nullptr, n, rocprim::plus<u32>(), (hipStream_t)0);
     L.temp_bytes = t1 > t2 ? t1 : t2;
     if (t3 > L.temp_bytes) L.temp_bytes = t3;
+    if (t4 > L.temp_bytes) L.temp_bytes = t4;
     L.temp = take(L.temp_bytes + 256);
     L.total = off;
     return L;
@@ -210,11 +255,11 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     unsigned blocks = (unsigned)ceil_div64(nv, 256);
     hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny, kzy_a, idx_b);
     if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 48, s) != hipSuccess) return TOMO_E_LAUNCH;
-    hipLaunchKernelGGL(uq_heads_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, head, (u64 *)totals + 2);
     tb = L.temp_bytes;
-    if (rocprim::inclusive_scan(temp, tb, head, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
-    hipLaunchKernelGGL(uq_scatter_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)head,
-                       (const u32 *)hscan, uniq, rank, (u64 *)totals);
+    auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{vpos, (const u32 *)idx_c});
+    if (rocprim::inclusive_scan(temp, tb, heads, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(uq_scatter_check_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)hscan,
+                       uniq, rank, (u64 *)totals);
     return tomo_status();
 }
 
