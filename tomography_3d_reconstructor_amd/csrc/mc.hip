@@ -42,6 +42,8 @@ struct McGrid {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));      // one 12-byte store per vertex / triangle
+typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
 
 __device__ static inline u64 make_key(int64_t row, int X, int slot)
 {
@@ -491,19 +493,19 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
     if (flags & 1) {
         vkey[vo] = key | 0ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = fZ; p[1] = fY; p[2] = (float)((double)c.X + mc_edge_offset(c.v[0], c.v[1]));
+        *(float3u *)p = (float3u){fZ, fY, (float)((double)c.X + mc_edge_offset(c.v[0], c.v[1]))};
         vo++;
     }
     if (flags & 2) {
         vkey[vo] = key | 1ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = fZ; p[1] = (float)((double)c.Y + mc_edge_offset(c.v[0], c.v[3])); p[2] = fX;
+        *(float3u *)p = (float3u){fZ, (float)((double)c.Y + mc_edge_offset(c.v[0], c.v[3])), fX};
         vo++;
     }
     if (flags & 4) {
         vkey[vo] = key | 2ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = (float)((double)Zg + mc_edge_offset(c.v[0], c.v[4])); p[1] = fY; p[2] = fX;
+        *(float3u *)p = (float3u){(float)((double)Zg + mc_edge_offset(c.v[0], c.v[4])), fY, fX};
         vo++;
     }
     if (flags & 8) {
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
         mc_centre_offset(c.v, &ox, &oy, &oz);
         vkey[vo] = key | 3ull;
         float *p = vpos + 3 * (int64_t)vo;
-        p[0] = (float)((double)Zg + oz); p[1] = (float)((double)c.Y + oy); p[2] = (float)((double)c.X + ox);
+        *(float3u *)p = (float3u){(float)((double)Zg + oz), (float)((double)c.Y + oy), (float)((double)c.X + ox)};
         vo++;
     }
     if (!(c.cell_ok && c.index != 0 && c.index != 255)) return;
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
             tv[j] = (int32_t)v;
         }
         int32_t *fp = faces + 3 * (int64_t)fo;
-        fp[0] = tv[2]; fp[1] = tv[1]; fp[2] = tv[0];   // np.fliplr(faces) of the skimage wrapper
+        *(int3u *)fp = (int3u){tv[2], tv[1], tv[0]};    // np.fliplr(faces) of the skimage wrapper
         fo++;
     }
     if (bad) atomicAdd(&totals[3], 1ull);
