@@ -10,7 +10,7 @@
 //
 // Kernel structure (memory-bound: 1 bit in, 4 B out per padded voxel) -- "tile sparse":
 //   * the field row is cut into TILES of 32 float columns (one 128-byte line) x 16 rows; float column c
-//     of a row holds the value of extended bit c + 4 (tomo_extend_bits materialises every border rule, so
+//     of a row holds the value of extended bit c + 4 (the extended bit volume carries every border rule, so
 //     there is not a single boundary branch here: pad columns, reflected columns and the unused columns of
 //     the pitch are ordinary outputs);
 //   * a block owns 4 consecutive slices x 16 rows x (up to 64) tiles.  It stages its 8 x 20 input rows of

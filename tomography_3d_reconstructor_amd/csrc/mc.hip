@@ -8,16 +8,16 @@
 //     the iso level along the edge (every MC33 tiling uses exactly the bichromatic edges of its cube);
 //     a centre vertex exists iff the cell's tiling row contains a 12;
 //   * pass 1 never touches the float field: the field kernel leaves one SIGN BIT per voxel behind (32-byte
-//     records per row and 256-column segment), and the ACTIVE voxels (8 cube corners not all on one side)
-//     of a segment follow from the records of four rows with a few 64-bit operations per segment
-//     (1.25 bit/voxel of traffic instead of 4 B/voxel); fields that did not come from the field kernel
-//     get their sign records from field_signs_kernel;
-//   * scan -> offsets; pass 2 writes the compact, ordered list of active voxels (surface-sized);
+//     records per row and 256-column segment, stored only for 16-row groups that are not constant -- a class byte
+//     per group says which), and the ACTIVE voxels (8 cube corners not all on one side) of a segment follow from
+//     the records of four rows with a few 64-bit operations per segment; fields that did not come from the field
+//     kernel get their sign records from field_signs_kernel;
+//   * scan (rocPRIM, single pass) -> offsets; pass 2 writes the compact, ordered list of active voxels;
 //   * pass 3 evaluates MC33 once per active voxel, ONE VOXEL PER LANE (full lane utilisation for the
 //     branchy code), giving triangle and vertex counts; scan -> output offsets;
 //   * pass 4 writes vertices and triangles at their final positions: triangle order == the reference's
-//     cell scan order, LUT order inside a cell; triangle corners are resolved to vertex indices by a
-//     search in the active list restricted to the owner voxel's segment (a handful of entries).
+//     cell scan order, LUT order inside a cell; triangle corners are resolved to vertex indices through ONE list
+//     lookup per owner voxel: position = segment offset + rank of the voxel's bit in the segment's ballots.
 // No atomics decide any position: output is deterministic.
 #include <cstring>
 #include <cstdlib>

@@ -64,9 +64,9 @@ def main():
             t_mc = timeit(lambda: pipeline.marching_cubes(f, 0.5), n=3, warm=1)
         else:
             t_mc = float("nan")
-        print("%-10s n=%d memset %.3f ms (%.0f GB/s) pack %.3f ms (%.0f GB/s) | ext %.3f | field %.3f ms (%.0f GB/s alg) + signs_finish %.3f | classify %.3f ms (%.0f GB/s) | "
+        print("%-10s n=%d memset %.3f ms (%.0f GB/s) pack %.3f ms (%.0f GB/s) | ext %.3f | field %.3f ms (%.0f GB/s alg) | classify %.3f ms (%.0f GB/s) | "
               "smooth %.3f | close %.3f | mc_total %.3f" % (
-                  name, n, t_zero, data.numel() * 4 / t_zero / 1e6, t_pack, n ** 3 / t_pack / 1e6, t_ext, t_field, 5 * Np / t_field / 1e6, t_fin, t_cls,
+                  name, n, t_zero, data.numel() * 4 / t_zero / 1e6, t_pack, n ** 3 / t_pack / 1e6, t_ext, t_field, 5 * Np / t_field / 1e6, t_cls,
                   4 * Np / t_cls / 1e6, t_morph, t_close, t_mc), flush=True)
         del vol, ext, data, f, seg_act, signs
         torch.cuda.empty_cache()
