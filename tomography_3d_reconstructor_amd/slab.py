@@ -95,8 +95,16 @@ class ThreadComm:
         self.rank, self.world = rank, world
         self.q, self.barrier, self.slots = queues, barrier, gather_slots
 
+    @staticmethod
+    def _publish(t):
+        """A copy of t that is COMPLETE when another thread (working on its own stream) picks it up."""
+        c = t.clone()
+        if c.is_cuda:
+            torch.cuda.current_stream(c.device).synchronize()
+        return c
+
     def send(self, t, dst):
-        self.q[(self.rank, dst)].put(t.clone())
+        self.q[(self.rank, dst)].put(self._publish(t))
 
     def recv(self, src, dtype):
         return self.q[(src, self.rank)].get(timeout=120)
@@ -112,7 +120,7 @@ class ThreadComm:
         return from_prev, from_next
 
     def all_gather(self, t):
-        self.slots[self.rank] = t.clone()
+        self.slots[self.rank] = self._publish(t)
         self.barrier.wait()
         out = [self.slots[i] for i in range(self.world)]
         self.barrier.wait()

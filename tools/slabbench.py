@@ -14,10 +14,16 @@ nzr = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ny = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 nx = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 dev = torch.device("cuda:0")
+if os.environ.get("TOMO_EXT"):            # debugging switches
+    pipeline.FIELD_FROM_BITS = False
+if os.environ.get("TOMO_SLAB_NOFAST"):
+    for m in ("unique_mc", "lookup", "remap_faces"):
+        delattr(slab.HipEngine, m)
 gz = nzr * world
 depths = np.full(gz, 1.0)
 steps = 6
 times = []
+results = [None] * world
 bar = threading.Barrier(world)
 
 
@@ -34,6 +40,7 @@ def target(c):
             bar.wait()
             if c.rank == 0 and it >= 2:
                 times.append(time.perf_counter() - t0)
+        results[c.rank] = (v, f, job.vertex_offset, job.n_vertices_global)
 
 
 ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
@@ -50,5 +57,22 @@ for it in range(steps + 2):
     pipeline.extract_surface(vol, d1, 1.0, 1.0)
 torch.cuda.synchronize()
 one_ms = (time.perf_counter() - t0) / steps * 1e3
+# the ranks' results, concatenated, must be the single-GPU mesh of the whole stack
+mg = pipeline.ellipsoid_mask(gz, ny, nx, dev).view(torch.uint8)
+volg = pipeline.smooth(pipeline.close_ends(pipeline.pack(mg), inplace=True), 3, True)
+gv, gf = pipeline.extract_surface(volg, depths, 1.0, 1.0)
+sv = torch.cat([r[0] for r in results]); sf = torch.cat([r[1] for r in results])
+same = bool(torch.equal(sv, gv) and torch.equal(sf, gf) and results[0][3] == gv.shape[0])
+print("slab result == single-GPU result:", same, "(%d vertices, %d faces)" % (gv.shape[0], gf.shape[0]), pipeline.COUNTERS)
+if not same:
+    print("  vertices: slab", tuple(sv.shape), "single", tuple(gv.shape), "| faces: slab", tuple(sf.shape), "single", tuple(gf.shape),
+          "| n_vertices_global", results[0][3], "| per rank", [(int(r[0].shape[0]), int(r[1].shape[0]), r[2]) for r in results])
+    if sv.shape == gv.shape:
+        d = torch.nonzero((sv != gv).any(1)).reshape(-1)
+        print("  vertex rows differing:", int(d.numel()), "first", d[:5].tolist(), sv[d[:3]].tolist(), gv[d[:3]].tolist())
+    if sf.shape == gf.shape:
+        d = torch.nonzero((sf != gf).any(1)).reshape(-1)
+        print("  face rows differing:", int(d.numel()), "first", d[:5].tolist(), sf[d[:3]].tolist(), gf[d[:3]].tolist())
+assert same
 print("world %d x (%d, %d, %d): slab step %.2f ms on one shared GPU = %.2f ms per rank; single pipeline on one slab-sized volume %.2f ms"
       % (world, nzr, ny, nx, slab_ms, slab_ms / world, one_ms))
