@@ -339,60 +339,54 @@ class SlabJob:
         first, last = self.rank == 0, self.rank == self.world - 1
         nv = vpos.shape[0]
         fast = vkey is not None and ny is not None and hasattr(e, "unique_mc")     # rows in marching-cubes order, with keys
+        # 1. ALL vertices of this rank: sorted unique rows + the index of every provisional vertex in them
+        if nv:
+            uniq, rank = e.unique_mc(vpos, vkey, ny) if fast else e.unique(vpos.contiguous())
+        else:
+            uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
         if self.world == 1:
-            if not nv:
-                uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
-            else:
-                uniq, rank = e.unique_mc(vpos, vkey, ny) if fast else e.unique(vpos)
             self.vertex_offset, self.n_vertices_global = 0, uniq.shape[0]
             return uniq, self._faces(faces32, rank.to(torch.int64))
-        # mapped z of the shared plane Zb = z1 + 1 (padded) through the same finalisation arithmetic
-        if not last:
+        # 2. the rows on the plane shared with rank+1 (mapped z of padded plane z1 + 1, through the same finalisation
+        #    arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1
+        nu, n_top = uniq.shape[0], 0
+        if not last and nu:
             zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
             if getattr(self, "_zb_key", None) != zkey:             # depends on the depth table only: once per table
                 zt = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
                 self._zb, self._zb_key = float(e.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
-            zb = self._zb
-            top = (vpos[:, 0] == zb) if nv else torch.zeros(0, dtype=torch.bool, device=dev)
-        else:
-            top = torch.zeros(nv, dtype=torch.bool, device=dev)
-        top_idx = torch.nonzero(top).reshape(-1)
-        keep_idx = torch.nonzero(~top).reshape(-1)
-        # how many shared-plane vertices arrive from below, then the vertices themselves
-        n_top = int(top_idx.numel())
+            n_top = int((uniq[:, 0] == self._zb).sum().item())
+        k = nu - n_top                                             # rows this rank keeps
+        # 3. they go up (count first); what arrives from below are copies of rows this rank has itself: look them up
         cnt_prev, _ = c.exchange(None, torch.tensor([n_top], dtype=torch.int64, device=dev), torch.int64)
         n_from_prev = int(cnt_prev.item()) if cnt_prev is not None else 0
-        from_prev, _ = c.exchange(None, vpos[top_idx].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
-        own = vpos[keep_idx]
-        n_own = own.shape[0]
-        prev_rows = from_prev.reshape(-1, 3) if from_prev is not None else own[:0]
-        uniq = rank = None
-        if fast and n_own:
-            # the rank's own vertices through the one-sort path; the few shared-plane vertices from below are copies of
-            # vertices this rank has itself, so they are looked up in its unique list instead of being sorted in
-            uniq, rank_own = e.unique_mc(own.contiguous(), vkey[keep_idx].contiguous(), ny)
-            idx_prev, missing = e.lookup(uniq, prev_rows.contiguous())
-            if missing == 0:
-                rank = torch.cat([rank_own, idx_prev], 0)
-            else:
-                uniq = None                                       # a vertex from below that is new here: sort everything
-        if uniq is None:
-            allv = torch.cat([own, prev_rows], 0)
-            if allv.shape[0]:
-                uniq, rank = e.unique(allv.contiguous())
-            else:
-                uniq, rank = allv, torch.zeros(0, dtype=torch.int32, device=dev)
-        # indices of the lower neighbour's top-plane vertices go back down
-        _, ids_next = c.exchange(rank[n_own:].contiguous(), None, torch.int32, recv_shape_next=(n_top,))
-        counts = c.all_gather(torch.tensor([uniq.shape[0]], dtype=torch.int64, device=dev))
+        from_prev, _ = c.exchange(None, uniq[k:].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
+        idx_prev = torch.zeros(0, dtype=torch.int32, device=dev)
+        if from_prev is not None and from_prev.shape[0]:
+            prev_rows = from_prev.reshape(-1, 3).contiguous()
+            missing = 1
+            if hasattr(e, "lookup") and nu:
+                idx_prev, missing = e.lookup(uniq, prev_rows)
+            if missing:
+                # a row from below that is new here (or an engine without lookup): merge the two sorted lists properly
+                merged, r2 = e.unique(torch.cat([uniq, prev_rows], 0).contiguous())
+                rank = r2[:nu][rank.to(torch.int64)]
+                idx_prev = r2[nu:]
+                uniq, nu = merged, merged.shape[0]
+                k = nu - n_top
+        # 4. their indices go back down; the kept counts give every rank its offset
+        _, ids_next = c.exchange(idx_prev.contiguous(), None, torch.int32, recv_shape_next=(n_top,))
+        counts = c.all_gather(torch.tensor([k], dtype=torch.int64, device=dev))
         counts = [int(x.item()) for x in counts]
         offs = np.concatenate([[0], np.cumsum(counts)])
         self.vertex_offset, self.n_vertices_global = int(offs[self.rank]), int(offs[-1])
-        gid = torch.empty(nv, dtype=torch.int64, device=dev)
-        gid[keep_idx] = rank[:n_own].to(torch.int64) + int(offs[self.rank])
-        if not last and top_idx.numel():
-            gid[top_idx] = ids_next.to(torch.int64) + int(offs[self.rank + 1])
-        return uniq, self._faces(faces32, gid)
+        # 5. global index of every provisional vertex: own rows by rank, shared-plane rows through the upper rank's ids
+        r64 = rank.to(torch.int64)
+        gid = r64 + int(offs[self.rank])
+        if n_top:
+            up = ids_next.to(torch.int64)[(r64 - k).clamp(min=0)] + int(offs[self.rank + 1])
+            gid = torch.where(r64 >= k, up, gid)
+        return uniq[:k], self._faces(faces32, gid)
 
     def _faces(self, faces32, gid):
         if faces32.shape[0] == 0:
