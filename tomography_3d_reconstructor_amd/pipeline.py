@@ -66,8 +66,9 @@ class RawMesh:
 
 
 # ----------------------------------------------------------------------------- binary stages
-def pack(mask: torch.Tensor) -> BitVolume:
-    """np.stack(mask_images) (voxel_processor.py:46) as a device uint8/bool tensor -> BitVolume."""
+def pack(mask: torch.Tensor, out: torch.Tensor = None) -> BitVolume:
+    """np.stack(mask_images) (voxel_processor.py:46) as a device uint8/bool tensor -> BitVolume (into `out`, a contiguous
+    int64 (nz, ny, words) tensor -- e.g. the middle of a halo-extended buffer -- when given)."""
     if mask.dim() != 3:
         raise ValueError("mask must be (nz, ny, nx)")
     if mask.dtype == torch.bool:
@@ -78,7 +79,12 @@ def pack(mask: torch.Tensor) -> BitVolume:
     nz, ny, nx = mask.shape
     L = _lib.lib()
     wx = L.tomo_words_per_row(nx)
-    bits = torch.empty((nz, ny, wx), dtype=torch.int64, device=mask.device)
+    if out is None:
+        bits = torch.empty((nz, ny, wx), dtype=torch.int64, device=mask.device)
+    else:
+        if tuple(out.shape) != (nz, ny, wx) or out.dtype != torch.int64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous int64 (nz, ny, words) tensor")
+        bits = out
     _lib.check(L.tomo_pack_bits(_p(mask), _p(bits), nz, ny, nx, _stream()), "tomo_pack_bits")
     return BitVolume(bits, (nz, ny, nx))
 

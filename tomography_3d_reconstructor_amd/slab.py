@@ -143,6 +143,16 @@ class HipEngine:
     def pack(self, mask):
         return pipeline.pack(mask)
 
+    def pack_into(self, mask, room):
+        """Pack the rank's slices into the middle of ONE buffer with `room` spare slices on either side, so that the
+        neighbour slices of the close-ends chain and the morphology halo are written next to them instead of being
+        concatenated (two copies of the whole slab less).  -> (buffer bits (nzl + 2 room, ny, words), BitVolume of the middle)."""
+        from . import _lib
+        nzl, ny, nx = mask.shape
+        wx = _lib.lib().tomo_words_per_row(nx)
+        buf = torch.empty((nzl + 2 * room, ny, wx), dtype=torch.int64, device=mask.device)
+        return buf, pipeline.pack(mask, out=buf[room:room + nzl])
+
     def bits(self, vol):
         return vol.bits
 
@@ -257,7 +267,8 @@ class SlabJob:
         self.active = None
 
     # -- step 1: closed slab (bits tensor of the owned slices)
-    def _close_ends(self, vol):
+    def _close_ends(self, vol, buf=None, room=0):
+        """buf / room: the halo-extended buffer `vol` sits in the middle of (HipEngine.pack_into), or None."""
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
         nzl = self.z1 - self.z0
@@ -271,8 +282,16 @@ class SlabJob:
             return e.bits(vol)
         # the original first slice of the next rank is the extra input of the chain
         _, nxt = c.exchange(bits[:1], None, torch.int64)
-        parts = ([] if first else [torch.zeros_like(bits[:1])]) + [bits] + ([] if last else [nxt])
-        ext = e.from_bits(torch.cat(parts, 0), (nzl + len(parts) - 1, self.ny, self.nx))
+        if buf is not None:     # the slice before (placeholder for the carry) and after (next rank's first) go in place
+            lo_i, hi_i = room - (0 if first else 1), room + nzl + (0 if last else 1)
+            if not last:
+                buf[room + nzl].copy_(nxt[0])
+            if not first:
+                buf[room - 1].zero_()
+            ext = e.from_bits(buf[lo_i:hi_i], (hi_i - lo_i, self.ny, self.nx))
+        else:
+            parts = ([] if first else [torch.zeros_like(bits[:1])]) + [bits] + ([] if last else [nxt])
+            ext = e.from_bits(torch.cat(parts, 0), (nzl + len(parts) - 1, self.ny, self.nx))
         G, P = e.close_gp(ext)
         gathered = c.all_gather(torch.stack([G, P, bits[0]], 0))
         carry = gathered[0][2]                                      # c'[0] = (filled) global slice 0
@@ -293,15 +312,27 @@ class SlabJob:
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
         nzl = self.z1 - self.z0
-        vol = e.pack(mask)
-        bits = self._close_ends(vol) if self.close_ends else e.bits(vol)
+        H = self.halo
+        buf = None
+        if self.world > 1 and hasattr(e, "pack_into"):
+            buf, vol = e.pack_into(mask, H)                 # the slab in the middle of its halo-extended buffer
+        else:
+            vol = e.pack(mask)
+        bits = self._close_ends(vol, buf, H) if self.close_ends else e.bits(vol)
         closed = e.from_bits(bits, (nzl, self.ny, self.nx))
         # halo for morphology + Gaussian
-        H = self.halo
         if self.world > 1:
             lo, hi = c.exchange(bits[:H], bits[nzl - H:], torch.int64)
-            parts = ([] if first else [lo]) + [bits] + ([] if last else [hi])
-            ext = e.from_bits(torch.cat(parts, 0), (nzl + (0 if first else H) + (0 if last else H), self.ny, self.nx))
+            if buf is not None:
+                if not first:
+                    buf[:H].copy_(lo)
+                if not last:
+                    buf[H + nzl:].copy_(hi)
+                a0, b0 = (H if first else 0), H + nzl + (0 if last else H)
+                ext = e.from_bits(buf[a0:b0], (b0 - a0, self.ny, self.nx))
+            else:
+                parts = ([] if first else [lo]) + [bits] + ([] if last else [hi])
+                ext = e.from_bits(torch.cat(parts, 0), (nzl + (0 if first else H) + (0 if last else H), self.ny, self.nx))
         else:
             ext = closed
         sm = e.smooth(ext, self.iterations, self.create_manifold)

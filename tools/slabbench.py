@@ -16,12 +16,14 @@ nx = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 dev = torch.device("cuda:0")
 if os.environ.get("TOMO_EXT"):            # debugging switches
     pipeline.FIELD_FROM_BITS = False
+if os.environ.get("TOMO_SLAB_NOPACKINTO"):
+    delattr(slab.HipEngine, "pack_into")
 if os.environ.get("TOMO_SLAB_NOFAST"):
     for m in ("unique_mc", "lookup", "remap_faces"):
         delattr(slab.HipEngine, m)
 gz = nzr * world
 depths = np.full(gz, 1.0)
-steps = 6
+steps = 12
 times = []
 results = [None] * world
 bar = threading.Barrier(world)
