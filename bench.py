@@ -140,7 +140,7 @@ def main():
         def step():
             return one_pass(mask, depths)
         total_voxels = nz * ny * nx
-        workload = "%dx%dx%d ellipsoid stack (BASELINE configs[2])" % (nx, ny, nz)
+        workload = "%dx%dx%d ellipsoid stack%s" % (nx, ny, nz, " (BASELINE configs[2])" if (nz, ny, nx) == (1024, 1024, 1024) else "")
         parallelism = "single"
 
     def barrier():
