@@ -186,11 +186,13 @@ int tomo_vertex_finalize(float *vpos, int64_t nv, int shift, const double *cum, 
 int64_t tomo_mesh_unique_workspace_bytes(int64_t nv);
 int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_t *rank, unsigned long long *totals,
                      void *workspace, int64_t workspace_bytes, void *stream);
-/* The same with ONE 48-bit radix sort (6 digit passes instead of 12), for rows in marching-cubes order together with the
- * vertex keys tomo_mc_emit wrote (vkey) and the field's row count Ny: exact if and only if totals[2] (which the caller
- * zeroes) is still 0 afterwards -- it counts the places where the result descends in (z, y, x) (float32 rounding
- * coincidences, zero slice depths); if it is not 0, call tomo_mesh_unique instead.  Same workspace. */
-int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey, int64_t nv, int Ny, float *uniq,
+/* The same through the one-sort path, for rows in marching-cubes order together with the vertex keys tomo_mc_emit wrote
+ * (vkey) and the field's Ny / Nz: the order is that of ONE stable sort on a 48-bit key (slice bucket, then y in a plane or
+ * z between planes), carried out as a stable two-way partition inside every slab plus a segmented 32-bit sort inside
+ * the 2 Nz buckets.  Exact if and only if totals[2] (which the caller zeroes) is still 0 afterwards -- it counts the places
+ * where the result descends in (z, y, x) (float32 rounding coincidences, zero slice depths); if it is not 0, call
+ * tomo_mesh_unique instead.  Same workspace. */
+int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey, int64_t nv, int Ny, int Nz, float *uniq,
                                int32_t *rank, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
                                void *stream);
 int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);

@@ -448,7 +448,7 @@ def test_unique_one_sort_path_detects_disorder_and_falls_back(dev):
         rank = torch.empty(len(v), dtype=torch.int32, device=dev)
         wsb = L.tomo_mesh_unique_workspace_bytes(len(v))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.check(L.tomo_mesh_unique_presorted(vt.data_ptr(), kt.data_ptr(), len(v), 1, uniq.data_ptr(), rank.data_ptr(),
+        _lib.check(L.tomo_mesh_unique_presorted(vt.data_ptr(), kt.data_ptr(), len(v), 1, 6 if ordered else 1, uniq.data_ptr(), rank.data_ptr(),
                                                 totals.data_ptr(), ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream),
                    "presorted")
         nviol = int(totals[2].item())
@@ -458,7 +458,7 @@ def test_unique_one_sort_path_detects_disorder_and_falls_back(dev):
             assert np.array_equal(uniq[: int(totals[0].item())].cpu().numpy(), eu)
             assert np.array_equal(rank.cpu().numpy(), einv.reshape(-1))
         mesh = pipeline.RawMesh(kt, vt, ft)
-        mesh._ny = 1
+        mesh._ny, mesh._nz = 1, (6 if ordered else 1)
         gv, gf = pipeline.ensure_manifold_mesh(mesh)
         ev, ef = O.ensure_manifold_mesh(v, f)
         assert np.array_equal(gv.cpu().numpy(), ev) and np.array_equal(gf.cpu().numpy(), ef)

@@ -65,7 +65,7 @@ SIGNATURES = {
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_unique": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
-    "tomo_mesh_unique_presorted": (_c_i, [_c_p, _c_p, _c_i64, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "tomo_mesh_unique_presorted": (_c_i, [_c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mesh_faces_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_lookup": (_c_i, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

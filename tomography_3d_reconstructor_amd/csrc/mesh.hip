@@ -165,8 +165,66 @@ __global__ __launch_bounds__(256) void uq_scatter_kernel(const float *__restrict
     if (i == nv - 1) totals[0] = (u64)hscan[i];
 }
 
+// ---- one-sort path, bucket partition + segmented sort
+// class of a vertex from its key: 1 = between two slice planes (z-edge / cell centre), 0 = in a plane
+struct UqBetween {
+    __host__ __device__ u32 operator()(u64 key) const { return (key & 3ull) >= 2ull ? 1u : 0u; }
+};
+
+// slab_start[Z] = index of the first vertex whose owner voxel is in slice >= Z (vertices arrive ordered by slice);
+// slab_start[0 .. Nz] inclusive, slab_start[Nz] = nv
+__global__ __launch_bounds__(256) void uq_slabs_kernel(const u64 *__restrict__ vkey, int64_t nv, int Ny, int Nz,
+                                                       u32 *__restrict__ slab_start)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    int64_t Z = (int64_t)((vkey[i] >> TOMO_KEY_ROW_SHIFT) / (u64)Ny);
+    if (Z > Nz - 1) Z = Nz - 1;
+    int64_t Zp = i == 0 ? -1 : (int64_t)((vkey[i - 1] >> TOMO_KEY_ROW_SHIFT) / (u64)Ny);
+    if (Zp > Nz - 1) Zp = Nz - 1;
+    for (int64_t z = Zp + 1; z <= Z; z++) slab_start[z] = (u32)i;
+    if (i == nv - 1) for (int64_t z = Z + 1; z <= Nz; z++) slab_start[z] = (u32)nv;
+}
+
+// stable partition of every slab into [in-plane vertices][between-plane vertices]: B[i] = number of between-plane
+// vertices before i.  Writes the 32-bit sub key (y in a plane, z between planes) and the source index at the
+// destination, and the segment offsets (2 Z -> plane part of slab Z, 2 Z + 1 -> between part; offsets[2 Nz] = nv).
+__global__ __launch_bounds__(256) void uq_partition_kernel(const float *__restrict__ vpos, const u64 *__restrict__ vkey,
+                                                           int64_t nv, int Ny, int Nz, const u32 *__restrict__ B,
+                                                           const u32 *__restrict__ slab_start, u32 *__restrict__ keys,
+                                                           u32 *__restrict__ idx, u32 *__restrict__ offsets)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)Nz) {                                   // the first Nz threads also publish the segment offsets
+        const u32 s0 = slab_start[i], s1 = slab_start[i + 1];
+        const u32 nb = B[s1] - B[s0];
+        offsets[2 * i] = s0;
+        offsets[2 * i + 1] = s1 - nb;
+        if (i == Nz - 1) offsets[2 * (int64_t)Nz] = (u32)nv;
+    }
+    if (i >= nv) return;
+    const u64 k = vkey[i];
+    int64_t Z = (int64_t)((k >> TOMO_KEY_ROW_SHIFT) / (u64)Ny);
+    if (Z > Nz - 1) Z = Nz - 1;
+    const bool between = (k & 3ull) >= 2ull;
+    const u32 s0 = slab_start[Z], s1 = slab_start[Z + 1];
+    const u32 b0 = B[s0], bi = B[i];
+    const u32 nplane = (s1 - s0) - (B[s1] - b0);
+    const u32 dest = between ? s0 + nplane + (bi - b0) : s0 + ((u32)i - s0) - (bi - b0);
+    const float *p = vpos + 3 * i;
+    keys[dest] = fkey32(between ? p[0] : p[1]);
+    idx[dest] = (u32)i;
+}
+
+__global__ void uq_total_kernel(const u64 *__restrict__ vkey, int64_t nv, u32 *__restrict__ B)
+{   // closes the exclusive scan: B[nv] = number of between-plane vertices
+    if (threadIdx.x == 0 && blockIdx.x == 0) B[nv] = B[nv - 1] + (((vkey[nv - 1] & 3ull) >= 2ull) ? 1u : 0u);
+}
+
+#define UQ_MAX_SLABS 65536          // slices the bucket tables of the one-sort path are sized for
+
 struct UqLayout {
-    size_t kx_a, kx_b, idx_a, idx_b, idx_c, kzy_a, kzy_b, head, hscan, temp, temp_bytes, total;
+    size_t kx_a, kx_b, idx_a, idx_b, idx_c, kzy_a, kzy_b, head, hscan, seg, temp, temp_bytes, total;
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -180,6 +238,7 @@ static UqLayout uq_layout(int64_t nv)
     L.idx_a = take(n * 4); L.idx_b = take(n * 4); L.idx_c = take(n * 4);
     L.kzy_a = take(n * 8); L.kzy_b = take(n * 8);
     L.head = take(n * 4); L.hscan = take(n * 4);
+    L.seg = take((size_t)(3 * UQ_MAX_SLABS + 16) * 4);              // slab_start[Nz + 1] | offsets[2 Nz + 1]
     size_t t1 = 0, t2 = 0, t3 = 0;
     (void)rocprim::radix_sort_pairs(nullptr, t1, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, n, 0, 32,
                               (hipStream_t)0);
@@ -192,6 +251,14 @@ static UqLayout uq_layout(int64_t nv)
     L.temp_bytes = t1 > t2 ? t1 : t2;
     if (t3 > L.temp_bytes) L.temp_bytes = t3;
     if (t4 > L.temp_bytes) L.temp_bytes = t4;
+    size_t t5 = 0, t6 = 0;
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, t5, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
+                                              (unsigned)n, (unsigned)(2 * UQ_MAX_SLABS), (const u32 *)nullptr, (const u32 *)nullptr,
+                                              0, 32, (hipStream_t)0);
+    auto cls = rocprim::make_transform_iterator((const u64 *)nullptr, UqBetween());
+    (void)rocprim::exclusive_scan(nullptr, t6, cls, (u32 *)nullptr, 0u, n + 1, rocprim::plus<u32>(), (hipStream_t)0);
+    if (t5 > L.temp_bytes) L.temp_bytes = t5;
+    if (t6 > L.temp_bytes) L.temp_bytes = t6;
     L.temp = take(L.temp_bytes + 256);
     L.total = off;
     return L;
@@ -237,9 +304,9 @@ TOMO_API int tomo_mesh_unique(const float *vpos, int64_t nv, float *uniq, int32_
 // on a plane / row value) or a zero slice depth can break it; every place where the result descends is counted in
 // totals[2] and the caller must then redo the call with tomo_mesh_unique (exact if and only if totals[2] == 0).
 // vkey: the keys tomo_mc_emit wrote (row << key_row_shift | x << 2 | slot, row = Z * Ny + Y).  Same workspace size.
-TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey, int64_t nv, int Ny, float *uniq,
-                                        int32_t *rank, unsigned long long *totals, void *workspace, int64_t workspace_bytes,
-                                        void *stream)
+TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long long *vkey, int64_t nv, int Ny, int Nz,
+                                        float *uniq, int32_t *rank, unsigned long long *totals, void *workspace,
+                                        int64_t workspace_bytes, void *stream)
 {
     if (!vpos || !vkey || !uniq || !rank || !totals || !workspace || nv <= 0 || Ny <= 0) return TOMO_E_ARG;
     if (nv >= 0x7fffffffll) return TOMO_E_SIZE;
@@ -253,8 +320,30 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     size_t tb = L.temp_bytes;
     hipStream_t s = (hipStream_t)stream;
     unsigned blocks = (unsigned)ceil_div64(nv, 256);
-    hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny, kzy_a, idx_b);
-    if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 48, s) != hipSuccess) return TOMO_E_LAUNCH;
+    static const bool global_sort = getenv("TOMO_UQ_GLOBAL_SORT") != nullptr;     // A/B switch: one 48-bit device-wide sort
+    if (global_sort || Nz <= 0 || Nz > UQ_MAX_SLABS) {
+        hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny,
+                           kzy_a, idx_b);
+        if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 48, s) != hipSuccess) return TOMO_E_LAUNCH;
+    } else {
+        // The bucket (slice, in-plane / between planes) part of that key needs no device-wide sort: vertices arrive grouped
+        // by slice, so it is a stable two-way partition inside every slab (one scan + one scatter); what remains is a
+        // 32-bit sort INSIDE each of the 2 Nz buckets -- a segmented sort, one pass over the data, no look-back chain.
+        u32 *kx_a = (u32 *)(ws + L.kx_a), *kx_b = (u32 *)(ws + L.kx_b);
+        u32 *Bscan = (u32 *)kzy_a;                                   // nv + 1 entries (the 64-bit key area is free here)
+        u32 *slab_start = (u32 *)(ws + L.seg), *offsets = slab_start + UQ_MAX_SLABS + 8;
+        unsigned blocks2 = (unsigned)ceil_div64(nv > Nz ? nv : Nz, 256);
+        hipLaunchKernelGGL(uq_slabs_kernel, dim3(blocks), dim3(256), 0, s, (const u64 *)vkey, nv, Ny, Nz, slab_start);
+        auto cls = rocprim::make_transform_iterator((const u64 *)vkey, UqBetween());
+        if (rocprim::exclusive_scan(temp, tb, cls, Bscan, 0u, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
+        hipLaunchKernelGGL(uq_total_kernel, dim3(1), dim3(64), 0, s, (const u64 *)vkey, nv, Bscan);
+        hipLaunchKernelGGL(uq_partition_kernel, dim3(blocks2), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, Ny, Nz,
+                           (const u32 *)Bscan, (const u32 *)slab_start, kx_a, idx_b, offsets);
+        tb = L.temp_bytes;
+        if (rocprim::segmented_radix_sort_pairs(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
+                                                (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s) != hipSuccess)
+            return TOMO_E_LAUNCH;
+    }
     tb = L.temp_bytes;
     auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{vpos, (const u32 *)idx_c});
     if (rocprim::inclusive_scan(temp, tb, heads, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;

@@ -291,7 +291,8 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
                               int(z_offset), _p(vkey), _p(vpos), _p(faces32), _p(tot2), st), "tomo_mc_emit")
     mesh = RawMesh(vkey, vpos, faces32[:nf])
     mesh._mc = (f, geo, vox_key, na, seg_act, seg_aoff, vox_voff, vox_flags)   # for first_touch_order (manifold=False)
-    mesh._ny = f.Ny       # rows of the field: the one-sort unique path derives the slice of a vertex from its key
+    mesh._ny = f.Ny       # rows / slices of the field: the one-sort unique path derives the slice of a vertex from its key
+    mesh._nz = f.Nz
     mesh._stats_fresh = True
     mesh._stats = stats   # stats[7] != 0 would mean a triangle corner without vertex (read with the unique totals)
     return mesh
@@ -372,8 +373,9 @@ def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
         first = False
         totals = stats[8:12]
         if do_unique == "one_sort":
-            _lib.check(L.tomo_mesh_unique_presorted(_p(mesh.vpos), _p(mesh.vkey), nv, int(ny), _p(uniq), _p(rank), _p(totals),
-                                                    _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
+            _lib.check(L.tomo_mesh_unique_presorted(_p(mesh.vpos), _p(mesh.vkey), nv, int(ny), int(getattr(mesh, "_nz", 0) or 0),
+                                                    _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
+                       "tomo_mesh_unique_presorted")
         elif do_unique == "general":
             _lib.check(L.tomo_mesh_unique(_p(mesh.vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()),
                        "tomo_mesh_unique")
@@ -407,7 +409,7 @@ def ensure_manifold_mesh(mesh: RawMesh, presorted: bool = True):
     return verts, faces
 
 
-def unique_rows(vpos: torch.Tensor, vkey: torch.Tensor = None, ny: int = None):
+def unique_rows(vpos: torch.Tensor, vkey: torch.Tensor = None, ny: int = None, nz: int = 0):
     """np.unique(rows, axis=0, return_inverse=True) of finalised vertex rows -> (uniq (U,3), rank (V,) int32).  With the
     marching-cubes keys of the rows (and the field's row count) the one-sort path is tried first."""
     L = _lib.lib()
@@ -424,8 +426,8 @@ def unique_rows(vpos: torch.Tensor, vkey: torch.Tensor = None, ny: int = None):
     while True:
         totals = torch.zeros(4, dtype=torch.int64, device=dev)
         if fast:
-            _lib.check(L.tomo_mesh_unique_presorted(_p(vpos), _p(vkey.contiguous()), nv, int(ny), _p(uniq), _p(rank), _p(totals),
-                                                    _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
+            _lib.check(L.tomo_mesh_unique_presorted(_p(vpos), _p(vkey.contiguous()), nv, int(ny), int(nz or 0), _p(uniq), _p(rank),
+                                                    _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_unique_presorted")
         else:
             _lib.check(L.tomo_mesh_unique(_p(vpos), nv, _p(uniq), _p(rank), _p(totals), _p(ws), wsb, _stream()), "tomo_mesh_unique")
         host = totals.cpu()

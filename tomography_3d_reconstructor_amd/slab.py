@@ -229,9 +229,9 @@ class HipEngine:
 
 
     # optional fast paths (engines without them -- the CPU oracle engine of the tests -- use unique() and torch ops)
-    def unique_mc(self, vpos, vkey, ny):
+    def unique_mc(self, vpos, vkey, ny, nz=0):
         """unique() for rows in marching-cubes order with their keys: one-sort path with automatic fallback."""
-        return pipeline.unique_rows(vpos, vkey, ny)
+        return pipeline.unique_rows(vpos, vkey, ny, nz)
 
     def lookup(self, uniq, query):
         return pipeline.lookup_rows(uniq, query)
@@ -361,6 +361,7 @@ class SlabJob:
         else:
             vpos, faces32 = mesh.vpos, mesh.faces32
             vkey, ny = getattr(mesh, "vkey", None), getattr(mesh, "_ny", None)
+            self._mesh_nz = getattr(mesh, "_nz", 0)
             e.finalize_vertices(vpos, slice_depths, mm_y, mm_x)
         return self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
 
@@ -372,7 +373,7 @@ class SlabJob:
         fast = vkey is not None and ny is not None and hasattr(e, "unique_mc")     # rows in marching-cubes order, with keys
         # 1. ALL vertices of this rank: sorted unique rows + the index of every provisional vertex in them
         if nv:
-            uniq, rank = e.unique_mc(vpos, vkey, ny) if fast else e.unique(vpos.contiguous())
+            uniq, rank = e.unique_mc(vpos, vkey, ny, getattr(self, "_mesh_nz", 0)) if fast else e.unique(vpos.contiguous())
         else:
             uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
         if self.world == 1:
