@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void pack16_threshold_kernel(const uint8_t *__
     int x = g * 1024 + lane * 16;
     u32 piece = 0;
     if (x < nx) {
-        const uint4 v = *(const uint4 *)(grey + row * (int64_t)nx + x);
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load((const u4 *)(grey + row * (int64_t)nx + x));   // read once, keep it out of L2
         piece = ge_nibble(v.x, k2) | (ge_nibble(v.y, k2) << 4) | (ge_nibble(v.z, k2) << 8) | (ge_nibble(v.w, k2) << 12);
     }
     u64 w = (u64)piece << (16 * (lane & 3));
