@@ -77,6 +77,12 @@ __device__ static inline int reflect_near(int i, int n)
     return n < 2 ? 0 : (i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i));
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define ST4_NT(ptr, a, b, c, d) __builtin_nontemporal_store((f4v){a, b, c, d}, (f4v *)(ptr))
+#define ST4_PL(ptr, a, b, c, d) (*(float4 *)(ptr) = make_float4(a, b, c, d))
+// measured on the 1024^3 ellipsoid (bench, kernel ms): plain/plain 0.810, const nontemporal 0.796, both nontemporal 0.850
+#define ST4C ST4_NT     // constant tiles: whole-line streams nobody reads back soon
+#define ST4M ST4_PL     // mixed tiles: marching cubes reads exactly these lines next
 template <bool FROM_BITS>
 __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
                                                                 const FieldParams p)
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
                 const int c = s_cls[z][jl];
                 if (c < 2) {
                     const float kf = c ? c3f : 0.0f;
-                    *(float4 *)(zbase + (int64_t)row * p.pitch + 32 * jl) = make_float4(kf, kf, kf, kf);
+                    ST4C(zbase + (int64_t)row * p.pitch + 32 * jl, kf, kf, kf, kf);
                 }
             }
         }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
             const float o1 = (float)tap5(L3, q0, q1, q2, q3);                                           \
             const float o2 = (float)tap5(q0, q1, q2, q3, R0);                                           \
             const float o3 = (float)tap5(q1, q2, q3, R0, R1);                                           \
-            if (st && r < nrows) *(float4 *)orow = make_float4(o0, o1, o2, o3);                         \
+            if (st && r < nrows) ST4M(orow, o0, o1, o2, o3);                                            \
             orow += p.pitch;                                                                            \
             if (do_signs) {                                                                             \
                 const u64 b0 = __ballot(o0 > 0.5f), b1 = __ballot(o1 > 0.5f);                           \
