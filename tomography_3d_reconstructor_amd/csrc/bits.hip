@@ -5,6 +5,7 @@
 //
 // Reference lines replaced: voxel_processor.py:46 (stack), :51 (np.sum), :56-77 (close ends),
 // :79-97 (binary_opening + binary_closing with the 3-D cross, erosion border_value=True).
+#include <stdlib.h>
 #include "tomo_common.h"
 
 // ------------------------------------------------------------------------------------------
@@ -665,6 +666,210 @@ __global__ __launch_bounds__(256) void morph_wave_kernel(const u64 *__restrict__
 }
 #undef FW_LOAD
 
+
+// ------------------------------------------------------------------------------------------
+// Same wave-per-cross-section scheme, rewritten on 32-bit halves for the compile-time pass masks: gfx950's v_bitop3_b32
+// evaluates any 3-input boolean function in one instruction (the compiler only forms it from 32-bit expressions), which
+// makes a 6-neighbour erosion as cheap as a dilation and folds the z-border value into the combining op for free.
+// Per ring word and pass: out = Q op x, c = x masked, 2 alignbit + 2 DPP per half, two 3-input ops for the in-plane
+// cross, one for the z partner -- 9 VALU ops per half instead of ~15, and no register rotation: level j's input
+// alternates between two register sets by slice parity (loop unrolled by two), Q = inplane(s-1) op x(s-2) is carried.
+// The halo word is simply {low dword of the right neighbour word, high dword of the left one}: all 32 bits are real data.
+__device__ static inline u32 fw_out(int OP, u32 q, u32 x, u32 zo)
+{   // erosion: q & (x | zo)   dilation: q | (x & ~zo)      (zo: all ones where the slice lies outside the volume)
+    return OP == 0 ? __builtin_amdgcn_bitop3_b32(q, x, zo, 0xE0) : __builtin_amdgcn_bitop3_b32(q, x, zo, 0xF4);
+}
+__device__ static inline u32 fw_op3(int OP, u32 a, u32 b, u32 c)
+{
+    return OP == 0 ? __builtin_amdgcn_bitop3_b32(a, b, c, 0x80) : __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
+}
+
+// Memory side (STAGED): with lane = row every direct load or store instruction touches 64 different 128-byte lines, and
+// the texture addresser -- not bytes, not VALU -- then sets the kernel's time (TA_BUSY 90 %, waves in issue stall half
+// their life).  So global memory is accessed row-major instead -- 4 lanes x 16 B per row and instruction: a row's window
+// [w0 - 2, w0 + 6) words is one 64-byte piece of a line -- and a wave-private LDS image turns that into lane = row and
+// back (80- and 48-byte row pitches: conflict-free 16-byte LDS accesses).  Needs even wx and 16-byte aligned volumes;
+// everything else takes the direct path (STAGED = false).
+template <int H, int OPS, bool STAGED>
+__global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int nz, int ny,
+                                                              int nx, int wx, int zchunk, int nxt, int nyt, int64_t nwaves)
+{
+    constexpr int W = FW_W;
+    constexpr int LB_PITCH = 80, SB_PITCH = 48, WAVE_LDS = 64 * LB_PITCH + 64 * SB_PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGED ? 4 * WAVE_LDS : 16];
+    const int lane = threadIdx.x & 63;
+    // the wave index through readfirstlane: everything derived from it (slice range, loop counter, border flags) is
+    // then known to be wave-uniform and lives in SGPRs / scalar branches
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (wid >= nwaves) return;
+    const int xt = (int)(wid % nxt), yt = (int)((wid / nxt) % nyt), zc = (int)(wid / ((int64_t)nxt * nyt));
+    const int w0 = xt * W;
+    const int rows_own = 64 - 2 * H;
+    const int y0 = yt * rows_own, y = y0 - H + lane;
+    const int za = zc * zchunk, zb = za + zchunk < nz ? za + zchunk : nz;
+    const int zend = zb + H + 1;            // + 1: a slice is stored one iteration after it was finished (see below)
+    const bool rowv = y >= 0 && y < ny;
+    const bool own_row = rowv && lane >= H && lane < 64 - H;
+    const u64 tailmask = (nx & 63) ? ((1ull << (nx & 63)) - 1ull) : ~0ull;
+    const int64_t sw = (int64_t)ny * wx;
+    const int64_t rowoff = rowv ? (int64_t)y * wx : 0;
+    // Bits that lie outside the volume read as the pass's border value: orow (per lane) for rows beyond ny, mu (wave-
+    // uniform, SGPRs) for words beyond wx and the tail of the last word.
+    const u32 orow = rowv ? 0u : ~0u;
+    u32 mu[W + 1][2];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const u64 mk = (w0 + k >= wx) ? ~0ull : (w0 + k == wx - 1 ? ~tailmask : 0ull);
+        mu[k][0] = (u32)mk;
+        mu[k][1] = (u32)(mk >> 32);
+    }
+    mu[W][0] = (w0 + W >= wx) ? ~0u : (w0 + W == wx - 1 ? (u32)~tailmask : 0u);
+    mu[W][1] = (w0 - 1 < 0) ? ~0u : 0u;
+
+    u32 X[2][H + 1][W + 1][2], Q[H][W + 1][2];
+#pragma unroll
+    for (int k = 0; k <= W; k++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int j = 0; j <= H; j++) { X[0][j][k][h] = 0; X[1][j][k][h] = 0; }
+#pragma unroll
+            for (int j = 0; j < H; j++) Q[j][k][h] = 0;
+        }
+
+    // ---- direct path: addresses clamped into the volume; what is read from a clamped place is masked or replaced by zo
+    int wk[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wk[k] = w0 + k < wx ? w0 + k : wx - 1;
+    const int wl = w0 - 1 >= 0 ? w0 - 1 : 0, wr = w0 + W < wx ? w0 + W : wx - 1;
+    // ---- staged path: load instruction q covers rows 16 q .. 16 q + 15 (4 lanes a row), store instruction q rows
+    //      32 q .. 32 q + 31 (2 lanes a row)
+    unsigned char *lb = s_stage + (STAGED ? wv * WAVE_LDS : 0), *sb = lb + (STAGED ? 64 * LB_PITCH : 0);
+    uint4 G[4];
+    const int lrow = lane >> 2, lpart = lane & 3, lwp = w0 - 2 + 2 * lpart;       // first word of this lane's 16 bytes
+    const bool lpv = lwp >= 0 && lwp < wx;
+    const int srow = lane >> 1, spart = lane & 1, swp = w0 + 2 * spart;
+    const bool spv = swp < wx;
+
+#define FW_ISSUE(tt)                                                                             \
+    {                                                                                            \
+        const int tc = (tt) < 0 ? 0 : ((tt) >= nz ? nz - 1 : (tt));                              \
+        const u64 *sl = in + (int64_t)tc * sw;                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                          \
+            const int yy = y0 - H + 16 * q + lrow;                                               \
+            if (lpv && yy >= 0 && yy < ny) G[q] = *(const uint4 *)(sl + (int64_t)yy * wx + lwp); \
+        }                                                                                        \
+    }
+#define FW_LAND(dst)                                                                             \
+    {                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                            \
+            *(uint4 *)(lb + (16 * q + lrow) * LB_PITCH + 16 * lpart) = G[q];                     \
+        const uint4 a = *(const uint4 *)(lb + lane * LB_PITCH + 16);                             \
+        const uint4 b = *(const uint4 *)(lb + lane * LB_PITCH + 32);                             \
+        dst[0][0] = a.x; dst[0][1] = a.y; dst[1][0] = a.z; dst[1][1] = a.w;                      \
+        dst[2][0] = b.x; dst[2][1] = b.y; dst[3][0] = b.z; dst[3][1] = b.w;                      \
+        dst[W][1] = *(const u32 *)(lb + lane * LB_PITCH + 12);                                   \
+        dst[W][0] = *(const u32 *)(lb + lane * LB_PITCH + 48);                                   \
+    }
+#define FW_LOAD32(dst, tt)                                                                       \
+    {                                                                                            \
+        const int tc = (tt) < 0 ? 0 : ((tt) >= nz ? nz - 1 : (tt));                              \
+        const u32 *src = (const u32 *)(in + (int64_t)tc * sw + rowoff);                          \
+        _Pragma("unroll") for (int k = 0; k < W; k++) {                                          \
+            const uint2 v = *(const uint2 *)(src + 2 * wk[k]);                                   \
+            dst[k][0] = v.x; dst[k][1] = v.y;                                                    \
+        }                                                                                        \
+        dst[W][0] = src[2 * wr];                                                                 \
+        dst[W][1] = src[2 * wl + 1];                                                             \
+    }
+    if (STAGED) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) G[q] = make_uint4(0, 0, 0, 0);
+        FW_ISSUE(za - H);
+    } else {
+        FW_LOAD32(X[0][0], za - H);
+    }
+    for (int t0 = za - H; t0 < zend; t0 += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int t = t0 + p;
+            if (t < zend) {
+                if (STAGED) FW_LAND(X[p][0]);
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    const int OP = (OPS >> j) & 1;                  // a constant once the level loop is unrolled
+                    const int sX = t - j;
+                    const u32 zo = (sX >= 0 && sX < nz) ? 0u : ~0u;                  // wave-uniform
+                    const u32 zp = (sX - 1 >= 0 && sX - 1 < nz) ? 0u : ~0u;
+                    u32 C[W + 1][2];
+#pragma unroll
+                    for (int k = 0; k <= W; k++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const u32 x = X[p][j][k][h];
+                            X[p][j + 1][k][h] = fw_out(OP, Q[j][k][h], x, zo);
+                            // erosion: x | orow | mu     dilation: x & ~orow & ~mu
+                            C[k][h] = OP == 0 ? __builtin_amdgcn_bitop3_b32(x, orow, mu[k][h], 0xFE)
+                                              : __builtin_amdgcn_bitop3_b32(x, orow, mu[k][h], 0x10);
+                        }
+#pragma unroll
+                    for (int k = 0; k <= W; k++) {
+                        const int kp = k == 0 ? W : k - 1, kn = k == W ? 0 : k + 1;
+                        const u32 clo = C[k][0], chi = C[k][1], lin = C[kp][1], rin = C[kn][0];
+                        const u32 xl0 = __builtin_amdgcn_alignbit(clo, lin, 31), xl1 = __builtin_amdgcn_alignbit(chi, clo, 31);
+                        const u32 xh0 = __builtin_amdgcn_alignbit(chi, clo, 1), xh1 = __builtin_amdgcn_alignbit(rin, chi, 1);
+                        const u32 yl0 = (u32)__builtin_amdgcn_mov_dpp((int)clo, 0x138, 0xf, 0xf, true);
+                        const u32 yl1 = (u32)__builtin_amdgcn_mov_dpp((int)chi, 0x138, 0xf, 0xf, true);
+                        const u32 yh0 = (u32)__builtin_amdgcn_mov_dpp((int)clo, 0x130, 0xf, 0xf, true);
+                        const u32 yh1 = (u32)__builtin_amdgcn_mov_dpp((int)chi, 0x130, 0xf, 0xf, true);
+                        Q[j][k][0] = fw_out(OP, fw_op3(OP, fw_op3(OP, clo, yl0, yh0), xl0, xh0), X[p ^ 1][j][k][0], zp);
+                        Q[j][k][1] = fw_out(OP, fw_op3(OP, fw_op3(OP, chi, yl1, yh1), xl1, xh1), X[p ^ 1][j][k][1], zp);
+                    }
+                    if (j == 0) {
+                        // The slice finished in the previous iteration is stored here, before the next loads are issued
+                        // (the waitcnt in front of loaded data also covers every store issued before it).
+                        const int so = t - 1 - H;
+                        const bool sv = so >= za && so < zb;
+                        if (STAGED) {
+                            if (sv) {
+                                *(uint4 *)(sb + lane * SB_PITCH) =
+                                    make_uint4(X[p ^ 1][H][0][0] & ~mu[0][0], X[p ^ 1][H][0][1] & ~mu[0][1],
+                                               X[p ^ 1][H][1][0] & ~mu[1][0], X[p ^ 1][H][1][1] & ~mu[1][1]);
+                                *(uint4 *)(sb + lane * SB_PITCH + 16) =
+                                    make_uint4(X[p ^ 1][H][2][0] & ~mu[2][0], X[p ^ 1][H][2][1] & ~mu[2][1],
+                                               X[p ^ 1][H][3][0] & ~mu[3][0], X[p ^ 1][H][3][1] & ~mu[3][1]);
+                                u64 *sl = out + (int64_t)so * sw;
+#pragma unroll
+                                for (int q = 0; q < 2; q++) {
+                                    const int r = 32 * q + srow, yy = y0 - H + r;
+                                    const uint4 v = *(const uint4 *)(sb + r * SB_PITCH + 16 * spart);
+                                    if (spv && r >= H && r < 64 - H && yy >= 0 && yy < ny) *(uint4 *)(sl + (int64_t)yy * wx + swp) = v;
+                                }
+                            }
+                            FW_ISSUE(t + 1);
+                        } else {
+                            if (own_row && sv) {
+                                u32 *dst = (u32 *)(out + (int64_t)so * sw + rowoff);
+#pragma unroll
+                                for (int kk = 0; kk < W; kk++)
+                                    if (w0 + kk < wx)
+                                        *(uint2 *)(dst + 2 * (w0 + kk)) =
+                                            make_uint2(X[p ^ 1][H][kk][0] & ~mu[kk][0], X[p ^ 1][H][kk][1] & ~mu[kk][1]);
+                            }
+                            FW_LOAD32(X[p ^ 1][0], t + 1);      // in flight during the other levels (clamped, so always legal)
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // levels one after the other: interleaving them only costs registers
+                }
+            }
+        }
+    }
+}
+#undef FW_LOAD32
+#undef FW_LAND
+#undef FW_ISSUE
+
 template <int H>
 static int morph_wave_launch(const u64 *in, u64 *out, int nz, int ny, int nx, int wx, u32 ops, hipStream_t s)
 {
@@ -687,12 +892,25 @@ static int morph_wave_launch(const u64 *in, u64 *out, int nz, int ny, int nx, in
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
 #define FW_GO(OPSC) hipLaunchKernelGGL((morph_wave_kernel<H, OPSC>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, nz, ny, nx, \
                                        wx, ops, zchunk, nxt, nyt, nwaves)
+#define FW_GO32(OPSC)                                                                                                      \
+    {                                                                                                                      \
+        if (staged) hipLaunchKernelGGL((morph_wave32_kernel<H, OPSC, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, nz, \
+                                       ny, nx, wx, zchunk, nxt, nyt, nwaves);                                              \
+        else hipLaunchKernelGGL((morph_wave32_kernel<H, OPSC, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, nz, ny,  \
+                                nx, wx, zchunk, nxt, nyt, nwaves);                                                         \
+    }
+    // TOMO_MORPH_PATH = generic | direct : A/B switches for the tests (default: the fastest path that applies)
+    static const char *force = getenv("TOMO_MORPH_PATH");
+    const bool generic_only = force && force[0] == 'g';
+    const bool staged = !(force && force[0] == 'd') && (wx % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     // the pass masks of smooth_voxel_data: E D D E (opening + first closing), D E D E (two closings), D E, E D
-    if (H == 4 && ops == 6u) FW_GO(6);
-    else if (H == 4 && ops == 5u) FW_GO(5);
-    else if (H == 2 && ops == 1u) FW_GO(1);
-    else if (H == 2 && ops == 2u) FW_GO(2);
+    if (generic_only) FW_GO(-1);
+    else if (H == 4 && ops == 6u) FW_GO32(6)
+    else if (H == 4 && ops == 5u) FW_GO32(5)
+    else if (H == 2 && ops == 1u) FW_GO32(1)
+    else if (H == 2 && ops == 2u) FW_GO32(2)
     else FW_GO(-1);
+#undef FW_GO32
 #undef FW_GO
     return tomo_status();
 }
