@@ -90,7 +90,9 @@ def test_binary_stages_vs_oracle(dev, shape, p):
 
 
 @pytest.mark.parametrize("shape", [(20, 130, 257), (9, 70, 262), (37, 57, 320), (12, 120, 513), (70, 9, 64), (5, 200, 1025),
-                                   (11, 64, 255), (3, 1, 700), (1, 90, 129)])
+                                   (11, 64, 255), (3, 1, 700), (1, 90, 129),
+                                   # even word counts take the LDS-staged path: last strip of 2 words, tail in it / not
+                                   (20, 130, 384), (12, 120, 1000), (37, 57, 1090), (6, 300, 128), (50, 61, 1152)])
 @pytest.mark.parametrize("it,cm", [(3, True), (1, True), (2, False), (3, False), (0, True)])
 def test_smooth_tile_edges_vs_oracle(dev, shape, it, cm):
     """The one-wave-per-tile smoothing kernel: rows wider than a 4-word strip with the tail in every position relative
@@ -102,6 +104,32 @@ def test_smooth_tile_edges_vs_oracle(dev, shape, it, cm):
                                                                        shape[2] // 7 + 1)) < 0.5
     got = to_np(pipeline.smooth(to_vol(v, dev), it, cm))
     assert np.array_equal(got, O.smooth(v, it, cm))
+
+
+@pytest.mark.parametrize("path", ["generic", "direct"])
+def test_smooth_alternative_paths(path):
+    """The smoothing launcher picks the LDS-staged kernel when it applies; the direct and the generic (run-time pass
+    mask) kernels behind it are forced through TOMO_MORPH_PATH, which is read once per process -- hence the child."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        from tomography_3d_reconstructor_amd import pipeline
+        from oracle import oracle as O
+        dev = torch.device("cuda:0")
+        for shape in [(20, 130, 384), (37, 57, 1090), (9, 70, 262), (66, 64, 256)]:
+            rng = np.random.default_rng(shape[2])
+            v = rng.random(shape) < 0.8
+            v[:, : shape[1] // 3, -(shape[2] // 5 + 1):] = True
+            vol = pipeline.pack(torch.from_numpy(v.view(np.uint8)).to(dev))
+            for it, cm in [(3, True), (2, False)]:
+                got = pipeline.unpack(pipeline.smooth(vol, it, cm)).cpu().numpy().astype(bool)
+                assert np.array_equal(got, O.smooth(v, it, cm)), (shape, it, cm)
+        print("ok")
+    """)
+    env = dict(os.environ, TOMO_MORPH_PATH=path, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_fill_holes_spiral(dev):

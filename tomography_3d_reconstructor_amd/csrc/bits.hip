@@ -795,7 +795,29 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
         for (int p = 0; p < 2; p++) {
             const int t = t0 + p;
             if (t < zend) {
-                if (STAGED) FW_LAND(X[p][0]);
+                if (STAGED) {
+                    // top of the iteration: land the prefetched slice, store the slice finished in the previous iteration,
+                    // issue the next loads -- all before the first level, so the loads have the whole iteration to arrive
+                    FW_LAND(X[p][0]);
+                    const int so = t - 1 - H;
+                    const bool sv = so >= za && so < zb;
+                    if (sv) {
+                        *(uint4 *)(sb + lane * SB_PITCH) =
+                            make_uint4(X[p ^ 1][H][0][0] & ~mu[0][0], X[p ^ 1][H][0][1] & ~mu[0][1],
+                                       X[p ^ 1][H][1][0] & ~mu[1][0], X[p ^ 1][H][1][1] & ~mu[1][1]);
+                        *(uint4 *)(sb + lane * SB_PITCH + 16) =
+                            make_uint4(X[p ^ 1][H][2][0] & ~mu[2][0], X[p ^ 1][H][2][1] & ~mu[2][1],
+                                       X[p ^ 1][H][3][0] & ~mu[3][0], X[p ^ 1][H][3][1] & ~mu[3][1]);
+                        u64 *sl = out + (int64_t)so * sw;
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const int r = 32 * q + srow, yy = y0 - H + r;
+                            const uint4 v = *(const uint4 *)(sb + r * SB_PITCH + 16 * spart);
+                            if (spv && r >= H && r < 64 - H && yy >= 0 && yy < ny) *(uint4 *)(sl + (int64_t)yy * wx + swp) = v;
+                        }
+                    }
+                    FW_ISSUE(t + 1);
+                }
 #pragma unroll
                 for (int j = 0; j < H; j++) {
                     const int OP = (OPS >> j) & 1;                  // a constant once the level loop is unrolled
@@ -831,24 +853,7 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
                         // (the waitcnt in front of loaded data also covers every store issued before it).
                         const int so = t - 1 - H;
                         const bool sv = so >= za && so < zb;
-                        if (STAGED) {
-                            if (sv) {
-                                *(uint4 *)(sb + lane * SB_PITCH) =
-                                    make_uint4(X[p ^ 1][H][0][0] & ~mu[0][0], X[p ^ 1][H][0][1] & ~mu[0][1],
-                                               X[p ^ 1][H][1][0] & ~mu[1][0], X[p ^ 1][H][1][1] & ~mu[1][1]);
-                                *(uint4 *)(sb + lane * SB_PITCH + 16) =
-                                    make_uint4(X[p ^ 1][H][2][0] & ~mu[2][0], X[p ^ 1][H][2][1] & ~mu[2][1],
-                                               X[p ^ 1][H][3][0] & ~mu[3][0], X[p ^ 1][H][3][1] & ~mu[3][1]);
-                                u64 *sl = out + (int64_t)so * sw;
-#pragma unroll
-                                for (int q = 0; q < 2; q++) {
-                                    const int r = 32 * q + srow, yy = y0 - H + r;
-                                    const uint4 v = *(const uint4 *)(sb + r * SB_PITCH + 16 * spart);
-                                    if (spv && r >= H && r < 64 - H && yy >= 0 && yy < ny) *(uint4 *)(sl + (int64_t)yy * wx + swp) = v;
-                                }
-                            }
-                            FW_ISSUE(t + 1);
-                        } else {
+                        if (!STAGED) {
                             if (own_row && sv) {
                                 u32 *dst = (u32 *)(out + (int64_t)so * sw + rowoff);
 #pragma unroll
