@@ -18,10 +18,14 @@ out, pat = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if pat in r["Kernel_Name"]:
+        if any(q in r["Kernel_Name"] for q in pat.split("|")):
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
-    for c, v in sorted(d.items()):
-        print("   %-32s n=%d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+    g = lambda c: (sum(d[c]) / len(d[c])) if c in d and d[c] else float("nan")
+    wc = g("SQ_WAVE_CYCLES")
+    print("   waves %.0f  wave_cycles %.3g  active %.0f%%  wait_mem %.0f%%  wait_issue %.0f%%  valu/active %.0f%%  TA_busy %.3g  busy_cycles %.3g  vmem_insts %.3g  valu_insts %.3g  tcc_rd %.3g tcc_wr %.3g"
+          % (g("SQ_WAVES"), wc, 100 * g("SQ_ACTIVE_INST_ANY") / wc, 100 * g("SQ_WAIT_ANY") / wc, 100 * g("SQ_WAIT_INST_ANY") / wc,
+             100 * g("SQ_ACTIVE_INST_VALU") / g("SQ_ACTIVE_INST_ANY"), g("TA_BUSY_avr"), g("SQ_BUSY_CYCLES"), g("SQ_INSTS_VMEM"), g("SQ_INSTS_VALU"),
+             g("TCP_TCC_READ_REQ_sum"), g("TCP_TCC_WRITE_REQ_sum")))
 PY
