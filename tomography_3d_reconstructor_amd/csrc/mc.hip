@@ -537,30 +537,50 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
         if ((e1 || e9) && i + 1 < na && vox_key[i + 1] == key + 4ull) { base = vox_voff[i + 1]; fl = vox_flags[i + 1]; }
         id[1] = slot_vertex(base, fl, 1); id[9] = slot_vertex(base, fl, 2);
     }
-    {
-        u32 fl = 0, base = 0xffffffffu;
-        if (e2 || e11) base = find_owner(make_key(c.row + 1, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
-        id[2] = slot_vertex(base, fl, 0); id[11] = slot_vertex(base, fl, 2);
-    }
-    {
-        u32 fl = 0, base = 0xffffffffu;
-        if (e4 || e7) base = find_owner(make_key(c.row + rowY, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
-        id[4] = slot_vertex(base, fl, 0); id[7] = slot_vertex(base, fl, 1);
-    }
-    {
-        u32 fl = 0, base = 0xffffffffu;
-        if (e10) base = find_owner(make_key(c.row + 1, c.X + 1, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
-        id[10] = slot_vertex(base, fl, 2);
-    }
-    {
-        u32 fl = 0, base = 0xffffffffu;
-        if (e5) base = find_owner(make_key(c.row + rowY, c.X + 1, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
-        id[5] = slot_vertex(base, fl, 1);
-    }
-    {
-        u32 fl = 0, base = 0xffffffffu;
-        if (e6) base = find_owner(make_key(c.row + 1 + rowY, c.X, 0), g, seg_act, seg_aoff, vox_voff, vox_flags, &fl);
-        id[6] = slot_vertex(base, fl, 0);
+    {   // The five other owner voxels: (y+1), (z+1), (y+1,x+1), (z+1,x+1), (y+1,z+1).  Their lookups are three dependent
+        // loads each (segment offsets -> ballot record -> flags / vertex base); run as straight-line code in three
+        // phases, all five in flight per phase, instead of five branches that each serialise their own chain.
+        // A lookup that is not needed (edge not bichromatic) goes to this voxel's own key: always a valid address.
+        const bool need[5] = {e2 || e11, e4 || e7, e10, e5, e6};
+        const u64 okey[5] = {make_key(c.row + 1, c.X, 0), make_key(c.row + rowY, c.X, 0), make_key(c.row + 1, c.X + 1, 0),
+                             make_key(c.row + rowY, c.X + 1, 0), make_key(c.row + 1 + rowY, c.X, 0)};
+        u64 seg[5];
+        u32 cc[5], a0[5], a1[5];
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            const u64 k = need[n] ? okey[n] : key;
+            cc[n] = ((u32)(k >> 2) & ((1u << KEY_XBITS) - 1u)) + (u32)g.xorg + SEG_SHIFT;
+            seg[n] = (k >> (KEY_XBITS + 2)) * (u64)g.segs_per_row + (cc[n] >> 8);
+            a0[n] = seg_aoff[seg[n]];
+            a1[n] = seg_aoff[seg[n] + 1];
+        }
+        Rec4 rec[5];
+#pragma unroll
+        for (int n = 0; n < 5; n++) rec[n] = load_rec(seg_act, (int64_t)seg[n]);     // garbage for an empty segment: masked below
+        u32 pos[5];
+        bool have[5];
+#pragma unroll
+        for (int n = 0; n < 5; n++) {
+            const Rec4 &r = rec[n];
+            const int L = (int)((cc[n] & 255u) >> 2), k = (int)(cc[n] & 3u);
+            const u64 bk = k == 0 ? r.b[0] : (k == 1 ? r.b[1] : (k == 2 ? r.b[2] : r.b[3]));
+            const u64 m = (1ull << L) - 1ull;
+            u32 rank = (u32)(__popcll(r.b[0] & m) + __popcll(r.b[1] & m) + __popcll(r.b[2] & m) + __popcll(r.b[3] & m));
+            rank += (k > 0 ? (u32)((r.b[0] >> L) & 1ull) : 0u) + (k > 1 ? (u32)((r.b[1] >> L) & 1ull) : 0u) +
+                    (k > 2 ? (u32)((r.b[2] >> L) & 1ull) : 0u);
+            have[n] = need[n] && a1[n] != a0[n] && ((bk >> L) & 1ull);
+            pos[n] = have[n] ? a0[n] + rank : (u32)i;
+        }
+        u32 fl[5], base[5];
+#pragma unroll
+        for (int n = 0; n < 5; n++) { fl[n] = vox_flags[pos[n]]; base[n] = vox_voff[pos[n]]; }
+#pragma unroll
+        for (int n = 0; n < 5; n++) if (!have[n]) { fl[n] = 0; base[n] = 0xffffffffu; }
+        id[2] = slot_vertex(base[0], fl[0], 0); id[11] = slot_vertex(base[0], fl[0], 2);
+        id[4] = slot_vertex(base[1], fl[1], 0); id[7] = slot_vertex(base[1], fl[1], 1);
+        id[10] = slot_vertex(base[2], fl[2], 2);
+        id[5] = slot_vertex(base[3], fl[3], 1);
+        id[6] = slot_vertex(base[4], fl[4], 0);
     }
     bool bad = false;
     for (int tI = 0; tI < t.ntri; tI++) {
