@@ -517,7 +517,6 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
         vo++;
     }
     if (!(c.cell_ok && c.index != 0 && c.index != 255)) return;
-    McTiling t = mc_cell_tiling(c.v, c.index);
     u32 fo = vox_foff[i];
     const int64_t rowY = (int64_t)g.Ny;
     // Vertex index of every cube edge that carries one (the edge is bichromatic), ONE list lookup per owner voxel:
@@ -533,8 +532,10 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
     id[8] = slot_vertex(vox_voff[i], (u32)flags, 2);
     id[12] = slot_vertex(vox_voff[i], (u32)flags, 3);
     {   // (x+1, y, z): the next entry of the list if it is active at all (coalesced loads)
-        u32 fl = 0, base = 0xffffffffu;
-        if ((e1 || e9) && i + 1 < na && vox_key[i + 1] == key + 4ull) { base = vox_voff[i + 1]; fl = vox_flags[i + 1]; }
+        const int64_t in = i + 1 < na ? i + 1 : i;
+        const u64 kn = vox_key[in];
+        u32 base = vox_voff[in], fl = vox_flags[in];
+        if (!((e1 || e9) && kn == key + 4ull)) { base = 0xffffffffu; fl = 0; }
         id[1] = slot_vertex(base, fl, 1); id[9] = slot_vertex(base, fl, 2);
     }
     {   // The five other owner voxels: (y+1), (z+1), (y+1,x+1), (z+1,x+1), (y+1,z+1).  Their lookups are three dependent
@@ -582,6 +583,8 @@ __global__ __launch_bounds__(256) void mc_emit_kernel(const float *__restrict__ 
         id[5] = slot_vertex(base[3], fl[3], 1);
         id[6] = slot_vertex(base[4], fl[4], 0);
     }
+    // the tiling (table walks, the ambiguity tests) after the lookups were issued: their latency hides behind it
+    McTiling t = mc_cell_tiling(c.v, c.index);
     bool bad = false;
     for (int tI = 0; tI < t.ntri; tI++) {
         int32_t tv[3];
