@@ -104,6 +104,13 @@ int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, int nx, i
  * while it stages its input.  Same outputs as tomo_field_fill(gaussian = 1) on tomo_extend_bits(bits). */
 int tomo_field_fill_bits(const uint64_t *bits, float *field, int nz, int ny, int nx, int pad, unsigned long long *signs,
                          uint8_t *gcls, void *stream);
+/* The same, minus what nothing downstream can read: the float field is an intermediate of surface_extractor.py:43-55 that
+ * marching cubes reads only at the corners of active cells, so constant tiles whose input is uniform within 3 voxels stay
+ * unwritten (their floats are undefined afterwards).  Sign records / classes as above (both required here).  span_ws:
+ * 4-byte aligned device scratch of tomo_field_span_bytes(nz, ny, nx, pad) bytes. */
+int64_t tomo_field_span_bytes(int nz, int ny, int nx, int pad);
+int tomo_field_fill_bits_sparse(const uint64_t *bits, float *field, int nz, int ny, int nx, int pad, unsigned long long *signs,
+                                uint8_t *gcls, uint8_t *span_ws, void *stream);
 /* Sign records (input of marching-cubes pass 1): uint64 [Nz][S][NyP][4], S = tomo_mc_segments_per_row(Nx, xorg),
  * NyP = tomo_sign_rows(Ny) (Ny rounded up to 16 so that 16-row groups of records are 512-byte aligned);
  * bit L of word k of record (Z, s, Y) = [field(Z, Y, column 256 s - 224 + 4 L + k) > iso].  tomo_field_fill writes

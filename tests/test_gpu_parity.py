@@ -538,3 +538,62 @@ def test_whole_path_irregular_blobs_vs_oracle(dev):
     ev, ef = O.SurfaceExtractor().extract_manifold_surface(osm, depths, 0.31, 0.47)
     assert gv.cpu().numpy().tobytes() == ev.tobytes() and np.array_equal(gf.cpu().numpy(), ef)
     assert len(ev) > 50000 and any(pipeline.COUNTERS[k] != before[k] for k in pipeline.COUNTERS)
+
+
+# ------------------------------------------------------------------ sparse field
+@pytest.mark.parametrize("case", ["ellipsoid", "blobs", "noise", "touching", "wide", "thin", "nopad"])
+def test_sparse_field_same_mesh(dev, case):
+    """tomo_field_fill_bits_sparse leaves constant tiles unwritten that no marching-cubes cell can touch.  The buffer is
+    pre-filled with NaN here, so any read of an unwritten float would poison the mesh: mesh == the dense field's mesh,
+    bit for bit, and what is written equals the dense field."""
+    rng = np.random.default_rng(11)
+    if case == "ellipsoid":
+        v = np.asarray(O.ellipsoid_masks(96, 80, 40))
+    elif case == "blobs":
+        v = rng.random((30, 70, 150)) < 0.5
+        for _ in range(3):
+            v = O.smooth(v, 1, True)
+    elif case == "noise":
+        v = rng.random((12, 40, 90)) < 0.5
+    elif case == "touching":          # solid up to every border: the pad ring is the only zero in reach
+        v = np.ones((9, 37, 131), bool)
+        v[4, 20, 70] = False
+    elif case == "wide":              # several x chunks of the field kernel, tiles beyond the last column
+        v = np.zeros((6, 20, 2100), bool)
+        v[2:4, 5:15, 3:2098] = True
+    elif case == "thin":
+        v = np.zeros((5, 3, 33), bool)
+        v[2, 1, 5:30] = True
+    else:
+        v = np.asarray(O.ellipsoid_masks(48, 40, 24))
+    pad = case != "nopad"
+    vol = to_vol(v, dev)
+    L = pipeline._lib.lib()
+    nz, ny, nx = v.shape
+    p = 1 if pad else 0
+    fd = pipeline.make_field(vol, True, pad)
+    fs = pipeline.make_field(vol, True, pad, sparse=True)
+    assert fs.sparse and not fd.sparse
+    # the same call on an explicitly poisoned buffer
+    poisoned = torch.full_like(fs.data, float("nan"))
+    span = torch.empty(L.tomo_field_span_bytes(nz, ny, nx, p), dtype=torch.uint8, device=dev)
+    sb = torch.empty_like(fs.signs)
+    gc = torch.empty_like(fs.gcls)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.tomo_field_fill_bits_sparse(vol.bits.data_ptr(), poisoned.data_ptr(), nz, ny, nx, p, sb.data_ptr(), gc.data_ptr(),
+                                         span.data_ptr(), st) == 0
+    assert torch.equal(gc, fd.gcls)
+    written = ~torch.isnan(poisoned)
+    assert torch.equal(poisoned[written], fd.data[written])          # what is written is the dense field
+    fs.data = poisoned
+    fs.signs, fs.gcls = sb, gc
+    md, ms = pipeline.marching_cubes(fd, 0.5), pipeline.marching_cubes(fs, 0.5)
+    if md is None:
+        assert ms is None
+        return
+    assert torch.equal(md.vkey, ms.vkey) and torch.equal(md.faces32, ms.faces32)
+    assert torch.equal(md.vpos.view(torch.int32), ms.vpos.view(torch.int32))      # bitwise: no NaN got in
+    if case == "ellipsoid":
+        assert float(written.float().mean()) < 0.9                                 # and something was actually left out
+    with pytest.raises(Exception):
+        pipeline.marching_cubes(fs, 0.3)                                           # other levels need the dense field

@@ -48,6 +48,8 @@ SIGNATURES = {
     "tomo_extend_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_field_fill": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
     "tomo_field_fill_bits": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),
+    "tomo_field_span_bytes": (_c_i64, [_c_i, _c_i, _c_i, _c_i]),
+    "tomo_field_fill_bits_sparse": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p]),
     "tomo_sign_rows": (_c_i64, [_c_i]),
     "tomo_field_signs_fused": (_c_i, [_c_i]),
     "tomo_sign_buffer_words": (_c_i64, [_c_i, _c_i, _c_i, _c_i]),

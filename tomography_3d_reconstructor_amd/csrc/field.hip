@@ -26,6 +26,7 @@
 //     and no LDS exchange inside the row loop, full lanes for the float64 work;
 //   * the marching-cubes sign records ([field > 0.5], one bit per voxel) are a by-product: bytes of mixed
 //     tiles through LDS, bytes of constant tiles from the tile class, one 512-byte store per wave.
+#include <stdlib.h>
 #include "tomo_common.h"
 
 #define FW0 0x1.92b965ef5aaefp-1    // exp(-2 x^2)/sum for x = 0, +-1, +-2 as produced by the pinned
@@ -55,6 +56,10 @@ struct FieldParams {
                                     // (records not written), 2 = records written
     int S, NyP;
     int SB;                         // bytes per (slice, row, word k) line of the LDS sign area: tiles + 7, rounded up to 8
+    // sparse fill (all null = dense): comb[Z][tile row][tile] = 3 where the tile is within reach of the surface (bit 0: a 1,
+    // bit 1: a 0 within 3 voxels); list[0 .. *count) = linear ids of the blocks that have anything to do
+    const unsigned char *comb;
+    const u32 *list, *count;
 };
 
 __device__ static inline double tap5(double a, double b, double c, double d, double e)
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
 {
     __shared__ double s_lut[18];
     __shared__ unsigned char s_cls[FT_ZG][FT_SBMAX];
+    __shared__ unsigned short s_nlist[FT_ZG * FT_MAXT]; // (sparse fill) constant tiles within reach of the surface
+    __shared__ int s_nnear;
     __shared__ unsigned short s_list[FT_ZG * FT_MAXT];
     __shared__ int s_nmixed;
     __shared__ int s_zy[FT_SLOTS + FT_SROWS];       // (FROM_BITS) source slice / row of the staged slots / rows
@@ -100,9 +107,10 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         t += (double)s1 * FW1;
         s_lut[tid] = t;
     }
-    if (tid == 0) s_nmixed = 0;
+    if (tid == 0) { s_nmixed = 0; s_nnear = 0; }
     // ---- which part of the field is this block's
-    const unsigned lin = blockIdx.x;
+    if (p.list != nullptr && blockIdx.x >= *p.count) return;
+    const unsigned lin = p.list != nullptr ? p.list[blockIdx.x] : blockIdx.x;
     const int bx = (int)(lin % (unsigned)p.nxc);
     const int tr = (int)((lin / (unsigned)p.nxc) % (unsigned)p.ntr);
     const int zg = (int)(lin / ((unsigned)p.nxc * (unsigned)p.ntr));
@@ -117,6 +125,35 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     u32 *const s_bits = s_dyn;
     u32 *const s_ror = s_bits + FT_SLOTS * FT_SROWS * WS, *const s_rand = s_ror + FT_SLOTS * WS;
     unsigned char *const s_sign = (unsigned char *)(s_dyn + (((FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~1));
+    const int nrows = Y0 + FT_ROWS <= p.Ny ? FT_ROWS : p.Ny - Y0;
+    // ---- sign records of the block: per (slice, segment) 16 rows x 4 words = one 512-byte store per wave.
+    //      Byte b of a word = tile 8 (segment) - 7 + b: 0x00 / 0xff for a constant tile, the LDS byte for a mixed one.
+    auto write_signs = [&]()
+    {
+        const int nsegl = (nt + joff + 7) >> 3;
+        const int s0 = (j0 + 7) >> 3;
+        const int r = lane >> 2, k = lane & 3;
+        for (int it = wave; it < FT_ZG * nsegl; it += nwaves) {
+            const int z = it / nsegl, sl = it - z * nsegl;
+            const int Z = Z0 + z, s = s0 + sl;
+            if (Z >= p.Nz || s >= p.S) continue;
+            u64 cm = 0ull, mm = 0ull, vm = 0ull;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int jl = 8 * sl + b - joff;
+                const int c = (jl >= 0 && jl < nt) ? s_cls[z][jl] : 3;
+                if (c == 1) cm |= 0xffull << (8 * b);
+                if (c == 2) mm |= 0xffull << (8 * b);
+                if (c != 3) vm |= 0xffull << (8 * b);
+            }
+            // a group whose tiles are all constant and equal needs no records: marching cubes reads its class instead
+            const int gc = mm ? 2 : (cm == 0ull ? 0 : (cm == vm ? 1 : 2));
+            if (lane == 0) p.gcls[((int64_t)Z * (p.NyP >> 4) + tr) * p.S + s] = (unsigned char)gc;
+            if (gc != 2) continue;
+            const u64 v = cm | (*(const u64 *)(s_sign + ((z * FT_ROWS + r) * 4 + k) * SB + 8 * sl) & mm);
+            if (r < nrows) p.signs[((((int64_t)Z * p.S + s) * p.NyP) + Y0 + r) * 4 + k] = v;
+        }
+    };
 
     // ---- stage the block's input bits [slot][row][word] (slot = ext slice Z0 + slot, row = ext row Y0 + row, word = ext
     //      word j0 + widx); everything outside the extended volume reads as zero
@@ -229,6 +266,8 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         int c = o == 0u ? 0 : (a == 0xffffffffu ? 1 : 2);
         if (Z0 + z >= p.Nz) c = 3;
         s_cls[z][jl] = (unsigned char)c;
+        if (p.comb != nullptr && c < 2 && p.comb[((int64_t)(Z0 + z) * p.ntr + tr) * p.NT + j0 + jl] == 3)
+            s_nlist[atomicAdd(&s_nnear, 1)] = (unsigned short)((z << 8) | jl);      // constant, but within reach of the surface
         if (c == 2) s_list[atomicAdd(&s_nmixed, 1)] = (unsigned short)((z << 8) | jl);
     }
     __syncthreads();
@@ -238,12 +277,25 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     const double c2 = tap5(p1one, p1one, p1one, p1one, p1one);
     const double c3 = tap5(c2, c2, c2, c2, c2);
     const float c3f = (float)c3;
-    const int nrows = Y0 + FT_ROWS <= p.Ny ? FT_ROWS : p.Ny - Y0;
 
     // ---- constant tiles: whole-line float4 stores.  The block's part of a slice (16 rows x nt tiles) is swept as a
     //      flat, row-major list of 128-byte lines, 8 lines (1 KiB) per wave instruction, the four waves interleaved:
     //      the block writes each slice as one sequential stream (for rows of <= 57 tiles the region is contiguous).
-    {
+    if (p.comb != nullptr) {
+        // sparse fill: only the constant tiles within reach of the surface (a short list), one tile = two wave stores
+        const int ncl = s_nnear;
+        for (int ti = wave; ti < ncl; ti += nwaves) {
+            const u32 ent = (u32)s_nlist[ti];
+            const int z = (int)(ent >> 8), jl = (int)(ent & 0xffu);
+            const float kf = s_cls[z][jl] ? c3f : 0.0f;
+            float *tb = field + ((int64_t)(Z0 + z) * p.Ny + Y0) * p.pitch + 32 * (j0 + jl) + 4 * (lane & 7);
+#pragma unroll
+            for (int rr = 0; rr < FT_ROWS; rr += 8) {
+                const int row = rr + (lane >> 3);
+                if (row < nrows) ST4M(tb + (int64_t)row * p.pitch, kf, kf, kf, kf);
+            }
+        }
+    } else {
         const int nlines = nrows * nt;
         const float inv_nt = 1.0f / (float)nt;
         for (int z = 0; z < FT_ZG && Z0 + z < p.Nz; z++) {
@@ -342,33 +394,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     }
     if (p.signs == nullptr) return;
     __syncthreads();
-    // ---- sign records of the block: per (slice, segment) 16 rows x 4 words = one 512-byte store per wave.
-    //      Byte b of a word = tile 8 (segment) - 7 + b: 0x00 / 0xff for a constant tile, the LDS byte for a mixed one.
-    {
-        const int nsegl = (nt + joff + 7) >> 3;
-        const int s0 = (j0 + 7) >> 3;
-        const int r = lane >> 2, k = lane & 3;
-        for (int it = wave; it < FT_ZG * nsegl; it += nwaves) {
-            const int z = it / nsegl, sl = it - z * nsegl;
-            const int Z = Z0 + z, s = s0 + sl;
-            if (Z >= p.Nz || s >= p.S) continue;
-            u64 cm = 0ull, mm = 0ull, vm = 0ull;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const int jl = 8 * sl + b - joff;
-                const int c = (jl >= 0 && jl < nt) ? s_cls[z][jl] : 3;
-                if (c == 1) cm |= 0xffull << (8 * b);
-                if (c == 2) mm |= 0xffull << (8 * b);
-                if (c != 3) vm |= 0xffull << (8 * b);
-            }
-            // a group whose tiles are all constant and equal needs no records: marching cubes reads its class instead
-            const int gc = mm ? 2 : (cm == 0ull ? 0 : (cm == vm ? 1 : 2));
-            if (lane == 0) p.gcls[((int64_t)Z * (p.NyP >> 4) + tr) * p.S + s] = (unsigned char)gc;
-            if (gc != 2) continue;
-            const u64 v = cm | (*(const u64 *)(s_sign + ((z * FT_ROWS + r) * 4 + k) * SB + 8 * sl) & mm);
-            if (r < nrows) p.signs[((((int64_t)Z * p.S + s) * p.NyP) + Y0 + r) * 4 + k] = v;
-        }
-    }
+    write_signs();
 }
 
 // manifold=False: the field is the raw 0/1 volume (surface_extractor.py:46 without the Gaussian).
@@ -386,7 +412,8 @@ __global__ __launch_bounds__(256) void field_raw_kernel(const u64 *__restrict__ 
     field[((int64_t)Z * Ny + Y) * pitch + xorg + X] = (float)((w >> (e & 63)) & 1ull);
 }
 
-static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs, unsigned char *gcls)
+static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsigned long long *signs, unsigned char *gcls,
+                          int tp_force = 0)
 {
     p.Nz = nz + 2 * pad; p.Ny = ny + 2 * pad;
     const int Nx = nx + 2 * pad;
@@ -397,6 +424,10 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.NT = (int)(p.pitch / 32);
     p.nxc = (p.NT + 7 + FT_MAXT - 1) / FT_MAXT;
     p.tp = ((p.NT + 7 + p.nxc - 1) / p.nxc + 7) / 8 * 8;          // balanced chunks, still a multiple of 8 and <= FT_MAXT
+    if (tp_force) {                                                // sparse fill: short chunks, so that most blocks see no surface
+        p.tp = tp_force;
+        p.nxc = (p.NT + 7 + p.tp - 1) / p.tp;
+    }
     p.ntr = (p.Ny + FT_ROWS - 1) / FT_ROWS;
     p.nzg = (p.Nz + FT_ZG - 1) / FT_ZG;
     p.S = (int)tomo_mc_segments_per_row(Nx, tomo_field_xorg(pad));
@@ -405,11 +436,188 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.SW32 = 2 * (int)tomo_words_per_row(nx);
     p.signs = (u64 *)signs;
     p.gcls = gcls;
+    p.comb = nullptr; p.list = nullptr; p.count = nullptr;
     int ntmax = p.NT < p.tp ? p.NT : p.tp;           // tiles of the widest block
     int WS = ntmax + 1;
     size_t words = (((size_t)(FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~(size_t)1);
     p.SB = (ntmax + 7 + 7) & ~7;
     return words * sizeof(u32) + (signs ? (size_t)FT_ZG * FT_ROWS * 4 * p.SB : 0);
+}
+
+// ------------------------------------------------------------------------------------------ sparse fill
+// The float field is an intermediate: marching cubes reads it only at the corners of ACTIVE cells (and of the voxels that
+// own a vertex), i.e. within one voxel of a sign change.  A constant tile whose input is uniform within 3 voxels (2 for
+// the Gaussian's radius + 1 for the cell) in every direction can therefore stay unwritten.  span[Z][tile row][tile] says,
+// for ONE slice, whether the tile's reach (x and y extended by 3, positions outside the padded array ignored, the pad
+// ring = 0) holds a 1 (bit 0) and / or a 0 (bit 1); the field kernel ORs seven slices of it.
+#define FSPAN_Z 4                // slices of a block (one wave each)
+__global__ __launch_bounds__(64 * FSPAN_Z) void field_span_kernel(const u32 *__restrict__ b32, unsigned char *__restrict__ span,
+                                                                  int nz, int ny, int nx, int pad, int SW32, int Nz, int Ny,
+                                                                  int Nx, int NT, int ntr)
+{
+    // one block per (tile row tr, FSPAN_Z slices), one wave per slice: OR / AND of every 32-bit data word column over the
+    // data rows of the tile row's reach (one lane per column, the rows' loads in flight together), then one lane per tile
+    // looks at its 38 columns
+    extern __shared__ u32 s_oa[];                   // [FSPAN_Z][2][C]: OR, AND of data word w = c - 1, c = 0 .. C-1
+    const int C = NT + 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 *s_o = s_oa + wv * 2 * C, *s_a = s_o + C;
+    const int tr = (int)(blockIdx.x % (unsigned)ntr), Z = (int)(blockIdx.x / (unsigned)ntr) * FSPAN_Z + wv;
+    const int z = Z - pad;
+    const bool zdata = z >= 0 && z < nz;
+    // rows of the reach inside the padded array, and the data rows among them
+    const int Ya = tr * FT_ROWS - 3 < 0 ? 0 : tr * FT_ROWS - 3, Yb = tr * FT_ROWS + FT_ROWS + 3 < Ny ? tr * FT_ROWS + FT_ROWS + 3 : Ny;
+    const int ya = Ya - pad < 0 ? 0 : Ya - pad, yb = Yb - pad < ny ? Yb - pad : ny;      // data rows [ya, yb)
+    const bool ring_row = zdata && (Ya < pad || Yb > ny + pad);                           // a pad row within reach
+    if (Z < Nz) {
+        for (int c = lane; c < C; c += 64) {
+            const int w = c - 1;
+            u32 o = 0u, a = 0xffffffffu;
+            if (zdata && w >= 0 && w < SW32) {
+                const u32 *col = b32 + ((int64_t)z * ny) * SW32 + w;
+                for (int y0 = ya; y0 < yb; y0 += 12) {
+                    u32 v[12];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) v[k] = y0 + k < yb ? col[(int64_t)(y0 + k) * SW32] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) if (y0 + k < yb) { o |= v[k]; a &= v[k]; }
+                }
+            } else {
+                a = 0u;                              // no such data: handled through the valid / data masks below
+            }
+            s_o[c] = o; s_a[c] = a;
+        }
+    }
+    __syncthreads();
+    if (Z >= Nz) return;
+    for (int j = lane; j < NT; j += 64) {
+        const int X0 = 32 * j - 3;                              // padded column of window bit 0 (38 columns)
+        const int lo_i = X0 < 0 ? -X0 : 0, hi_i = Nx - X0 < 38 ? Nx - X0 : 38;
+        u32 f = 0u;
+        if (hi_i > lo_i && Yb > Ya) {
+            const u64 valid = ((1ull << hi_i) - 1ull) & ~((1ull << lo_i) - 1ull);
+            // data columns among the window: x = X0 - pad + i in [0, nx)
+            const int xs = X0 - pad;
+            const int dlo = -xs > 0 ? -xs : 0, dhi = nx - xs < 38 ? nx - xs : 38;
+            const u64 dmask = dhi > dlo ? (((1ull << dhi) - 1ull) & ~((1ull << dlo) - 1ull)) : 0ull;
+            u64 WO = 0ull, WA = 0ull;
+            if (zdata && yb > ya) {
+                const int w0 = xs >> 5, sh = xs & 31;            // arithmetic shift: floor; w0 >= -1
+                const int c0 = w0 + 1;                           // LDS index of data word w0
+                const u32 o0 = s_o[c0], o1 = c0 + 1 < C ? s_o[c0 + 1] : 0u, o2 = c0 + 2 < C ? s_o[c0 + 2] : 0u;
+                const u32 a0 = s_a[c0], a1 = c0 + 1 < C ? s_a[c0 + 1] : 0u, a2 = c0 + 2 < C ? s_a[c0 + 2] : 0u;
+                const u64 lo_o = ((u64)o1 << 32) | o0, lo_a = ((u64)a1 << 32) | a0;
+                WO = sh ? ((lo_o >> sh) | ((u64)o2 << (64 - sh))) : lo_o;
+                WA = sh ? ((lo_a >> sh) | ((u64)a2 << (64 - sh))) : lo_a;
+            }
+            const bool has_one = (WO & dmask) != 0ull;
+            // a zero: a pad slice / no data rows at all, a pad row or pad column within reach, or a zero data bit
+            const bool has_zero = !zdata || yb <= ya || ring_row || (valid & ~dmask) != 0ull || ((~WA) & dmask) != 0ull;
+            f = (has_one ? 1u : 0u) | (has_zero ? 2u : 0u);
+        }
+        span[((int64_t)Z * ntr + tr) * NT + j] = (unsigned char)f;
+    }
+}
+
+// comb = OR of the span bytes of slices Z-3 .. Z+3: 3 <=> the tile is within reach of the surface
+__global__ __launch_bounds__(256) void field_comb_kernel(const unsigned char *__restrict__ span, unsigned char *__restrict__ comb,
+                                                         int Nz, int64_t per_slice)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Nz * per_slice) return;
+    const int Z = (int)(i / per_slice);
+    u32 c = 0u;
+#pragma unroll
+    for (int k = -3; k <= 3; k++)
+        if (Z + k >= 0 && Z + k < Nz) c |= span[i + (int64_t)k * per_slice];
+    comb[i] = (unsigned char)c;
+}
+
+// One thread per block of the field kernel's (sparse) grid: 4 slices x one marching-cubes segment (8 tiles).  A block with
+// a tile within reach of the surface -- or with constant tiles of both kinds, whose records must be written -- goes on
+// the work list; every other block is done here: its groups are constant, only their class is recorded.
+__global__ __launch_bounds__(256) void field_worklist_kernel(const unsigned char *__restrict__ comb, FieldParams p,
+                                                             u32 *__restrict__ list, u32 *__restrict__ count)
+{
+    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= (int64_t)p.nxc * p.ntr * p.nzg) return;
+    const int bx = (int)(lin % p.nxc), tr = (int)((lin / p.nxc) % p.ntr), zg = (int)(lin / ((int64_t)p.nxc * p.ntr));
+    const int j0 = bx == 0 ? 0 : p.tp * bx - 7;
+    const int jend = p.tp * bx + p.tp - 7 < p.NT ? p.tp * bx + p.tp - 7 : p.NT;
+    // per slice and segment of the block: which kinds of constant tiles it has (1: ones, 2: zeros); 3 in reach => near
+    const int joff = (j0 + 7) & 7, nsegl = (jend - j0 + joff + 7) >> 3, s0 = (j0 + 7) >> 3;
+    bool near = false;
+    for (int z = 0; z < FT_ZG && !near; z++) {
+        const int Z = zg * FT_ZG + z;
+        if (Z >= p.Nz) continue;
+        const unsigned char *row = comb + ((int64_t)Z * p.ntr + tr) * p.NT;
+        for (int sl = 0; sl < nsegl; sl++) {
+            u32 kinds = 0u;
+            for (int b = 0; b < 8; b++) {
+                const int j = j0 + 8 * sl + b - joff;
+                if (j < j0 || j >= jend) continue;
+                const u32 c = row[j];
+                near |= c == 3u;
+                kinds |= c == 1u ? 1u : 2u;
+            }
+            near |= kinds == 3u;
+        }
+    }
+    if (near) { list[atomicAdd(count, 1u)] = (u32)lin; return; }
+    if (p.gcls == nullptr) return;
+    for (int z = 0; z < FT_ZG; z++) {
+        const int Z = zg * FT_ZG + z;
+        if (Z >= p.Nz) continue;
+        const unsigned char *row = comb + ((int64_t)Z * p.ntr + tr) * p.NT;
+        for (int sl = 0; sl < nsegl; sl++) {
+            if (s0 + sl >= p.S) continue;
+            int j = j0 + 8 * sl - joff;
+            if (j < j0) j = j0;
+            p.gcls[((int64_t)Z * (p.NyP >> 4) + tr) * p.S + s0 + sl] = (unsigned char)(row[j] == 1u ? 1 : 0);
+        }
+    }
+}
+
+static int ft_sparse_tp()
+{   // tile positions per block of the sparse grid (a multiple of 8 = whole marching-cubes segments)
+    static const int v = getenv("TOMO_SPARSE_TP") ? atoi(getenv("TOMO_SPARSE_TP")) : 16;
+    return v >= 8 && v <= FT_MAXT && v % 8 == 0 ? v : 16;
+}
+#define FT_SPARSE_TP ft_sparse_tp()
+TOMO_API int64_t tomo_field_span_bytes(int nz, int ny, int nx, int pad)
+{   // span + comb maps, the work list and its counter
+    FieldParams p;
+    (void)fill_params(p, nz, ny, nx, pad, nullptr, nullptr, FT_SPARSE_TP);
+    const int64_t tiles = (int64_t)p.Nz * p.ntr * p.NT, blocks = (int64_t)p.nxc * p.ntr * p.nzg;
+    return 2 * ((tiles + 63) / 64 * 64) + 4 * blocks + 256;
+}
+
+// tomo_field_fill_bits that leaves out what marching cubes cannot read (see above): `field` is only valid within one
+// voxel of the iso-surface's cells afterwards.  span_ws: tomo_field_span_bytes(...) bytes of device scratch.
+TOMO_API int tomo_field_fill_bits_sparse(const uint64_t *bits, float *field, int nz, int ny, int nx, int pad,
+                                         unsigned long long *signs, uint8_t *gcls, uint8_t *span_ws, void *stream)
+{
+    if (!bits || !field || !span_ws || !signs || !gcls || nz <= 0 || ny <= 0 || nx <= 0 || (pad != 0 && pad != 1))
+        return TOMO_E_ARG;
+    if (((uintptr_t)field & 127u) != 0 || ((uintptr_t)span_ws & 3u) != 0) return TOMO_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    FieldParams p;
+    size_t lds = fill_params(p, nz, ny, nx, pad, signs, gcls, FT_SPARSE_TP);
+    const int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg, sblocks = (int64_t)p.ntr * ((p.Nz + FSPAN_Z - 1) / FSPAN_Z);
+    const int64_t per_slice = (int64_t)p.ntr * p.NT, tiles = per_slice * p.Nz, tiles_al = (tiles + 63) / 64 * 64;
+    if (blocks > 0x7fffffff || sblocks > 0x7fffffff || ceil_div64(tiles, 256) > 0x7fffffff) return TOMO_E_SIZE;
+    unsigned char *span = span_ws, *comb = span_ws + tiles_al;
+    u32 *count = (u32 *)(span_ws + 2 * tiles_al), *list = count + 16;
+    if (hipMemsetAsync(count, 0, sizeof(u32), s) != hipSuccess) return TOMO_E_LAUNCH;
+    hipLaunchKernelGGL(field_span_kernel, dim3((unsigned)sblocks), dim3(64 * FSPAN_Z), (size_t)FSPAN_Z * 2 * (p.NT + 2) * sizeof(u32),
+                       s, (const u32 *)bits, span, nz, ny, nx, pad, p.SW32, p.Nz, p.Ny, nx + 2 * pad, p.NT, p.ntr);
+    hipLaunchKernelGGL(field_comb_kernel, dim3((unsigned)ceil_div64(tiles, 256)), dim3(256), 0, s, (const unsigned char *)span,
+                       comb, p.Nz, per_slice);
+    hipLaunchKernelGGL(field_worklist_kernel, dim3((unsigned)ceil_div64(blocks, 256)), dim3(256), 0, s, (const unsigned char *)comb,
+                       p, list, count);
+    p.comb = comb; p.list = list; p.count = count;
+    hipLaunchKernelGGL(field_tile_kernel<true>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)bits, field, p);
+    return tomo_status();
 }
 
 TOMO_API int tomo_field_signs_fused(int nx)

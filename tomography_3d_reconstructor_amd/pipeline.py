@@ -7,6 +7,7 @@ times these functions directly with the inputs already resident.
 
 Reference lines each function replaces are given in its docstring.
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -19,6 +20,9 @@ from . import _lib
 # it holds in this process is no longer tried first
 COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0, "faces_direct": 0, "faces_fallback": 0}
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
+# extract_surface: do not materialise the parts of the float field that marching cubes cannot read (same mesh, ~0.4 ms less
+# per 1024^3 pass).  Off by default: the reference's path, and bench.py's roofline, speak of a dense per-voxel field.
+FIELD_SPARSE = os.environ.get("TOMO_FIELD_SPARSE", "0") not in ("", "0")
 
 
 def _stream():
@@ -52,6 +56,7 @@ class Field:
     signs: torch.Tensor = None     # sign records (Nz, S, NyP, 4) int64 for `signs_level`, or None
     signs_level: float = 0.5
     gcls: torch.Tensor = None      # class of every 16-row group of records (Nz, NyP / 16, S) uint8: 0 / 1 constant, 2 stored
+    sparse: bool = False           # data holds floats only where marching cubes at signs_level reads them
 
     def dense(self):
         return self.data[:, :, self.xorg:self.xorg + self.Nx]
@@ -176,8 +181,11 @@ def smooth(vol: BitVolume, iterations: int = 3, create_manifold: bool = True) ->
 
 
 # ----------------------------------------------------------------------------- field
-def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) -> Field:
-    """surface_extractor.py:43-53 + float32 cast: the scalar field marching cubes reads."""
+def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True, sparse: bool = False) -> Field:
+    """surface_extractor.py:43-53 + float32 cast: the scalar field marching cubes reads.
+
+    sparse=True (Gaussian field from the bit volume only) leaves constant tiles that no marching-cubes cell at level 0.5
+    can touch unwritten: `data` is then valid only within one voxel of the surface's cells (Field.sparse is set)."""
     nz, ny, nx = vol.shape
     L = _lib.lib()
     pad = 1 if (manifold and add_padding) else 0
@@ -195,7 +203,13 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
         sbuf = torch.empty(L.tomo_sign_buffer_words(Nz, Ny, Nx, xorg), dtype=torch.int64, device=vol.device)
         signs = sbuf[: Nz * S * NyP * 4].view(Nz, S, NyP, 4)
         gcls = torch.empty((Nz, NyP // 16, S), dtype=torch.uint8, device=vol.device)
-    if manifold and FIELD_FROM_BITS:
+    is_sparse = False
+    if manifold and FIELD_FROM_BITS and sparse and fused:
+        span = torch.empty(L.tomo_field_span_bytes(nz, ny, nx, pad), dtype=torch.uint8, device=vol.device)
+        _lib.check(L.tomo_field_fill_bits_sparse(_p(vol.bits), _p(data), nz, ny, nx, pad, _p(sbuf), _p(gcls), _p(span), _stream()),
+                   "tomo_field_fill_bits_sparse")
+        is_sparse = True
+    elif manifold and FIELD_FROM_BITS:
         # the Gaussian field straight from the bit volume: border rules applied while the kernel stages its input
         _lib.check(L.tomo_field_fill_bits(_p(vol.bits), _p(data), nz, ny, nx, pad, _p(sbuf), _p(gcls), _stream()),
                    "tomo_field_fill_bits")
@@ -205,7 +219,9 @@ def make_field(vol: BitVolume, manifold: bool = True, add_padding: bool = True) 
         _lib.check(L.tomo_extend_bits(_p(vol.bits), _p(ext), nz, ny, nx, pad, _stream()), "tomo_extend_bits")
         _lib.check(L.tomo_field_fill(_p(ext), _p(data), nz, ny, nx, pad, 1 if manifold else 0, _p(sbuf), _p(gcls), _stream()),
                    "tomo_field_fill")
-    return Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5, gcls)
+    f = Field(data, Nz, Ny, Nx, pitch, xorg, signs, 0.5, gcls)
+    f.sparse = is_sparse
+    return f
 
 
 def field_signs(f: Field, level: float, z_begin: int = 0, z_end: int = None):
@@ -249,6 +265,8 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     nseg = f.Nz * f.Ny * spr
     # pass 1: active voxels per segment, scan, list of active segments
     if f.signs is None or f.signs_level != lvl:
+        if getattr(f, "sparse", False):
+            raise _lib.TomoError("a sparse field holds floats only near the 0.5 surface: other levels need make_field(sparse=False)")
         field_signs(f, lvl)
     seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)   # 32-byte record per NON-EMPTY segment
     seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)       # active voxels of every segment
@@ -511,7 +529,7 @@ def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x
     Returns (vertices (V,3) float32, faces (F,3) int64 -- int32 and skimage's numbering when manifold=False)
     device tensors, or None where the reference returns None.
     """
-    f = make_field(vol, manifold, add_padding)
+    f = make_field(vol, manifold, add_padding, sparse=FIELD_SPARSE)
     mesh = marching_cubes(f, 0.5)
     if mesh is None:
         return None
