@@ -315,7 +315,7 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     char *ws = (char *)workspace;
     u32 *idx_b = (u32 *)(ws + L.idx_b), *idx_c = (u32 *)(ws + L.idx_c);
     u64 *kzy_a = (u64 *)(ws + L.kzy_a), *kzy_b = (u64 *)(ws + L.kzy_b);
-    u32 *head = (u32 *)(ws + L.head), *hscan = (u32 *)(ws + L.hscan);
+    u32 *hscan = (u32 *)(ws + L.hscan);
     void *temp = ws + L.temp;
     size_t tb = L.temp_bytes;
     hipStream_t s = (hipStream_t)stream;
