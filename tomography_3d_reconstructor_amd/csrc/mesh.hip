@@ -229,6 +229,13 @@ struct UqLayout {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// The segments (one per slice plane / between-planes bucket) hold ~1 000 - 6 000 vertices at 1024^2 slices.  rocPRIM's default
+// (128 threads x 17 items) sorts at most 2 176 of them in one go and sends longer segments through several global-memory
+// passes of one small block: 512 x 8 keeps every segment up to 4 096 in registers / LDS (measured, unique stage at 1024^3:
+// default 0.43 ms, 256x16 0.32, 512x8 0.315, 1024x4 0.36, 512x6 0.35, 512x10 0.36, 256x24 0.39).
+typedef rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<512, 8>, rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>, true>
+    UqSegCfg;
+
 static UqLayout uq_layout(int64_t nv)
 {
     UqLayout L;
@@ -255,6 +262,13 @@ static UqLayout uq_layout(int64_t nv)
     (void)rocprim::segmented_radix_sort_pairs(nullptr, t5, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
                                               (unsigned)n, (unsigned)(2 * UQ_MAX_SLABS), (const u32 *)nullptr, (const u32 *)nullptr,
                                               0, 32, (hipStream_t)0);
+    {
+        size_t ta = 0;
+        (void)rocprim::segmented_radix_sort_pairs<UqSegCfg>(nullptr, ta, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
+                                                            (unsigned)n, (unsigned)(2 * UQ_MAX_SLABS), (const u32 *)nullptr,
+                                                            (const u32 *)nullptr, 0, 32, (hipStream_t)0);
+        if (ta > t5) t5 = ta;
+    }
     auto cls = rocprim::make_transform_iterator((const u64 *)nullptr, UqBetween());
     (void)rocprim::exclusive_scan(nullptr, t6, cls, (u32 *)nullptr, 0u, n + 1, rocprim::plus<u32>(), (hipStream_t)0);
     if (t5 > L.temp_bytes) L.temp_bytes = t5;
@@ -340,9 +354,15 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
         hipLaunchKernelGGL(uq_partition_kernel, dim3(blocks2), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, Ny, Nz,
                            (const u32 *)Bscan, (const u32 *)slab_start, kx_a, idx_b, offsets);
         tb = L.temp_bytes;
-        if (rocprim::segmented_radix_sort_pairs(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
-                                                (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s) != hipSuccess)
-            return TOMO_E_LAUNCH;
+        static const bool stock = getenv("TOMO_UQ_STOCK_SORTCFG") != nullptr;       // A/B switch: rocPRIM's default configuration
+        hipError_t e;
+        if (stock)
+            e = rocprim::segmented_radix_sort_pairs(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
+                                                    (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s);
+        else
+            e = rocprim::segmented_radix_sort_pairs<UqSegCfg>(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
+                                                              (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s);
+        if (e != hipSuccess) return TOMO_E_LAUNCH;
     }
     tb = L.temp_bytes;
     auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{vpos, (const u32 *)idx_c});
