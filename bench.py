@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--size", type=int, nargs=3, default=None, metavar=("NZ", "NY", "NX"),
                     help="per-rank volume (default 1024 1024 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1; gloo (halos staged through the host) only to rehearse the "
+                         "multi-rank code path with several ranks on ONE GPU -- never a measurement")
     ap.add_argument("--sparse-field", action="store_true",
                     help="opt-in: do not materialise the parts of the float field that marching cubes cannot read "
                          "(same mesh; NOT the headline configuration -- the roofline entry then only carries a note)")
@@ -115,11 +118,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    if args.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)        # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group("gloo")
     nz, ny, nx = args.size if args.size else (1024, 1024, 1024)
 
     timer = FieldTimer()
@@ -138,7 +146,7 @@ def main():
             return job.run(mask, depths, 1.0, 1.0)
         total_voxels = gz * ny * nx
         workload = "%dx%dx%d ellipsoid stack, Z-slabs of %d slices over %d GPUs (halos over RCCL)" % (nx, ny, gz, nz, world)
-        parallelism = "zslab%d" % world
+        parallelism = "zslab%d" % world + ("" if args.backend == "nccl" else " (REHEARSAL over gloo, not a measurement)")
     else:
         mask = pipeline.ellipsoid_mask(nz, ny, nx, dev).view(torch.uint8)
         depths = np.full(nz, 1.0)
@@ -168,8 +176,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions of this script live
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -196,7 +205,7 @@ def main():
     nverts = int(res[0].shape[0]) if res else 0
     nfaces = int(res[1].shape[0]) if res else 0
     if dist:
-        cnt = torch.tensor([nverts, nfaces], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([nverts, nfaces], dtype=torch.int64, device=rdev)
         td.all_reduce(cnt)
         nverts, nfaces = [int(x) for x in cnt.cpu()]
     out = {

@@ -42,6 +42,9 @@ class TorchDistComm:
         self.rank = td.get_rank()
         self.world = td.get_world_size()
         self.device = device
+        # gloo moves host memory only: device tensors are staged through the host then (a rehearsal path -- several ranks
+        # sharing one GPU, where RCCL refuses to start; the product path is "nccl" = RCCL with device buffers end to end)
+        self.stage_host = td.get_backend() == "gloo" and torch.device(device).type != "cpu"
 
     @staticmethod
     def _bytes(t):
@@ -77,12 +80,29 @@ class TorchDistComm:
                 from_next = torch.empty(shape, dtype=dtype, device=self.device)
                 if from_next.numel():
                     ops.append(td.P2POp(td.irecv, self._bytes(from_next), r + 1))
-        if ops:
+        if ops and self.stage_host:
+            staged = []
+            hops = []
+            for op in ops:
+                h = op.tensor.cpu() if op.op is td.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                staged.append((op, h))
+                hops.append(td.P2POp(op.op, h, op.peer))
+            for q in td.batch_isend_irecv(hops):
+                q.wait()
+            for op, h in staged:
+                if op.op is td.irecv:
+                    op.tensor.copy_(h)
+        elif ops:
             for q in td.batch_isend_irecv(ops):
                 q.wait()
         return from_prev, from_next
 
     def all_gather(self, t):
+        if self.stage_host:
+            h = t.contiguous().cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            self.td.all_gather(out, h)
+            return [o.to(self.device) for o in out]
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(out, t.contiguous())
         return out
