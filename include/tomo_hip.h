@@ -158,6 +158,15 @@ int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, con
  * vox_flags[na] = bit0/1/2 edge vertices, bit3 centre vertex. */
 int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
                  const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags, void *stream);
+/* Capped variants: the caller launches them BEFORE it has read the segment scan's total (one host round trip less per
+ * pass).  `cap` entries of buffer; list: segments that would not fit are skipped; eval: entries at and beyond *na_dev
+ * (device memory) get count 0, so tomo_mc_scan over all `cap` counts yields the same totals.  The caller checks
+ * na <= cap afterwards and falls back to the exact calls otherwise. */
+int tomo_mc_list_capped(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                        unsigned long long *vox_key, int64_t cap, void *stream);
+int tomo_mc_eval_capped(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                        const unsigned long long *vox_key, int64_t cap, const unsigned long long *na_dev,
+                        uint32_t *vox_counts, uint8_t *vox_flags, void *stream);
 /* 4. emit: vertices (key + raw MC position, (z,y,x) float32 as skimage returns them; keys ascending) and
  * triangles as provisional vertex indices (int32), in the reference's order and with the per-triangle
  * reversal of skimage/measure/_marching_cubes_lewiner.py:338.  totals[3] counts corners whose vertex was

@@ -597,3 +597,40 @@ def test_sparse_field_same_mesh(dev, case):
         assert float(written.float().mean()) < 0.9                                 # and something was actually left out
     with pytest.raises(Exception):
         pipeline.marching_cubes(fs, 0.3)                                           # other levels need the dense field
+
+
+# ------------------------------------------------------------------ size hints
+def test_marching_cubes_size_hints(dev):
+    """A second field of the same geometry launches list / eval / scan ahead of the first count download, into buffers
+    sized from the previous list: same mesh when the hint holds, when it is far too large, and when it is too small
+    (the guarded kernels must not touch anything, the plain path redoes the stage)."""
+    rng = np.random.default_rng(5)
+    shape = (24, 60, 140)
+    small = np.zeros(shape, bool); small[10:14, 20:30, 30:60] = True
+    big = rng.random(shape) < 0.5                                   # noise: a far longer active-voxel list
+    empty = np.zeros(shape, bool)
+    assert pipeline.NA_HINTS
+
+    def mesh_of(v, hints):
+        pipeline.NA_HINTS = hints
+        try:
+            f = pipeline.make_field(to_vol(v, dev))
+            m = pipeline.marching_cubes(f, 0.5)
+        finally:
+            pipeline.NA_HINTS = True
+        return None if m is None else (m.vkey.clone(), m.vpos.clone(), m.faces32.clone())
+
+    ref = {k: mesh_of(v, False) for k, v in (("small", small), ("big", big), ("empty", empty))}
+    pipeline._NA_HINT.clear()
+    c0 = dict(pipeline.COUNTERS)
+    order = ["small", "small", "big", "big", "small", "empty", "small"]     # no hint, hit, miss (too short), hit, hit (too long), ...
+    vols = {"small": small, "big": big, "empty": empty}
+    for k in order:
+        got = mesh_of(vols[k], True)
+        if ref[k] is None:
+            assert got is None
+            continue
+        for a, b in zip(got, ref[k]):
+            assert torch.equal(a, b), k
+    assert pipeline.COUNTERS.get("na_hint_miss", 0) - c0.get("na_hint_miss", 0) >= 1
+    assert pipeline.COUNTERS.get("na_hint_hit", 0) - c0.get("na_hint_hit", 0) >= 3

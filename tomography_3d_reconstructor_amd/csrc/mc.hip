@@ -302,11 +302,12 @@ TOMO_API int tomo_mc_scan_segments(const uint32_t *seg_cnt, int64_t nseg, uint32
 // ballots written by pass 1 into voxel keys, in x order
 __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
                                                       const u64 *__restrict__ seg_act, int64_t nseg,
-                                                      u64 *__restrict__ vox_key)
+                                                      u64 *__restrict__ vox_key, u32 cap)
 {
     int64_t seg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= nseg) return;
     if (seg_aoff[seg + 1] == seg_aoff[seg]) return;             // empty: its ballot record was never written
+    if (seg_aoff[seg + 1] > cap) return;                        // (capped call) the list is longer than the buffer: the caller redoes it
     int s = (int)(seg % g.segs_per_row);
     int64_t row = seg / g.segs_per_row;
     const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
@@ -326,8 +327,26 @@ __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 
     }
 }
 
+static int mc_list_launch(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                          unsigned long long *vox_key, u32 cap, void *stream);
+
 TOMO_API int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
                           unsigned long long *vox_key, void *stream)
+{
+    return mc_list_launch(Nz, Ny, Nx, xorg, seg_aoff, seg_act, vox_key, 0xffffffffu, stream);
+}
+
+// The same into a buffer of `cap` keys whose sufficiency the caller has not checked yet (it launches ahead of reading the
+// segment scan's total): segments that would not fit are skipped, nothing is written past the buffer.
+TOMO_API int tomo_mc_list_capped(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                                 unsigned long long *vox_key, int64_t cap, void *stream)
+{
+    if (cap <= 0 || cap >= 0xffffffffll) return TOMO_E_ARG;
+    return mc_list_launch(Nz, Ny, Nx, xorg, seg_aoff, seg_act, vox_key, (u32)cap, stream);
+}
+
+static int mc_list_launch(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const unsigned long long *seg_act,
+                          unsigned long long *vox_key, u32 cap, void *stream)
 {
     if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_aoff || !seg_act || !vox_key) return TOMO_E_ARG;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
@@ -336,7 +355,7 @@ TOMO_API int tomo_mc_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_
     int64_t blocks = ceil_div64(nseg, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_list_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, seg_aoff,
-                       (const u64 *)seg_act, nseg, (u64 *)vox_key);
+                       (const u64 *)seg_act, nseg, (u64 *)vox_key, cap);
     return tomo_status();
 }
 
@@ -386,10 +405,21 @@ __device__ static inline void load_cell(const float *__restrict__ field, const M
 
 __global__ __launch_bounds__(256) void mc_eval_kernel(const float *__restrict__ field, const McGrid g,
                                                       const u64 *__restrict__ vox_key, int64_t na,
-                                                      u32 *__restrict__ vox_counts, uint8_t *__restrict__ vox_flags)
+                                                      u32 *__restrict__ vox_counts, uint8_t *__restrict__ vox_flags,
+                                                      const u64 *__restrict__ na_dev)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na) return;
+    if (na_dev != nullptr) {
+        // (capped call) entries beyond the list count as nothing in the scan; a list longer than the buffer was not written
+        // completely (tomo_mc_list_capped skips what does not fit), so none of its keys may be trusted -- the caller redoes it
+        const u64 nad = *na_dev;
+        if (nad > (u64)na || (u64)i >= nad) {
+            vox_counts[i] = 0u;
+            vox_flags[i] = 0;
+            return;
+        }
+    }
     Cell c;
     load_cell(field, g, vox_key[i], c);
     int ntri = 0;
@@ -402,9 +432,30 @@ __global__ __launch_bounds__(256) void mc_eval_kernel(const float *__restrict__ 
     vox_flags[i] = (uint8_t)c.flags;
 }
 
+static int mc_eval_launch(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                          const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags,
+                          const unsigned long long *na_dev, void *stream);
+
 TOMO_API int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
                           const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags,
                           void *stream)
+{
+    return mc_eval_launch(field, Nz, Ny, Nx, pitch, xorg, iso, vox_key, na, vox_counts, vox_flags, nullptr, stream);
+}
+
+// The same over a list buffer of `cap` entries of which only the first *na_dev (device memory, e.g. the total of the
+// segment scan) are valid: the rest get count 0, so a scan over all `cap` counts gives the same totals.
+TOMO_API int tomo_mc_eval_capped(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                                 const unsigned long long *vox_key, int64_t cap, const unsigned long long *na_dev,
+                                 uint32_t *vox_counts, uint8_t *vox_flags, void *stream)
+{
+    if (!na_dev) return TOMO_E_ARG;
+    return mc_eval_launch(field, Nz, Ny, Nx, pitch, xorg, iso, vox_key, cap, vox_counts, vox_flags, na_dev, stream);
+}
+
+static int mc_eval_launch(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                          const unsigned long long *vox_key, int64_t na, uint32_t *vox_counts, uint8_t *vox_flags,
+                          const unsigned long long *na_dev, void *stream)
 {
     McGrid g;
     int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
@@ -414,7 +465,7 @@ TOMO_API int tomo_mc_eval(const float *field, int Nz, int Ny, int Nx, int64_t pi
     int64_t blocks = ceil_div64(na, 256);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, field, g,
-                       (const u64 *)vox_key, na, vox_counts, vox_flags);
+                       (const u64 *)vox_key, na, vox_counts, vox_flags, (const u64 *)na_dev);
     return tomo_status();
 }
 

@@ -19,6 +19,8 @@ from . import _lib
 # how often the speculative kernels of ensure_manifold_mesh held / had to be redone; a path that fails more often than
 # it holds in this process is no longer tried first
 COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0, "faces_direct": 0, "faces_fallback": 0}
+NA_HINTS = os.environ.get("TOMO_NA_HINTS", "1") not in ("", "0")   # marching_cubes: launch ahead of the first count download
+_NA_HINT = {}
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
 # extract_surface: do not materialise the parts of the float field that marching cubes cannot read (same mesh, ~0.4 ms less
 # per 1024^3 pass).  Off by default: the reference's path, and bench.py's roofline, speak of a dense per-voxel field.
@@ -277,26 +279,59 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     wsb = L.tomo_mc_scan_workspace_bytes(nseg)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     _lib.check(L.tomo_mc_scan_segments(_p(seg_cnt), nseg, _p(seg_aoff), _p(totals), _p(ws), wsb, st), "tomo_mc_scan_segments")
-    na = int(totals[0].item())
+    # pass 2-3: compact voxel list, one MC33 evaluation per active voxel, scan of the counts.
+    # With a size hint (the list length of the last field of this geometry) the three launches go out BEFORE the segment
+    # scan's total has come back -- into buffers of hint + 25 % entries, guarded on the device -- and one download
+    # brings all counters; a list that turns out longer than the buffer is simply redone the plain way.
+    tot2 = totals[4:]
+    hint_key = (f.Nz, f.Ny, f.Nx)
+    hint = _NA_HINT.get(hint_key) if NA_HINTS else None
+    na = None
+    if hint:
+        cap = int(hint * 1.25) + 4096
+        if cap < 2 ** 31:
+            vox_key = torch.empty(cap, dtype=torch.int64, device=dev)
+            vox_counts = torch.empty(cap, dtype=torch.int32, device=dev)
+            vox_flags = torch.empty(cap, dtype=torch.uint8, device=dev)
+            vox_voff = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+            vox_foff = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+            wsb2 = L.tomo_mc_scan_workspace_bytes(cap)
+            ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+            _lib.check(L.tomo_mc_list_capped(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(vox_key), cap, st),
+                       "tomo_mc_list_capped")
+            _lib.check(L.tomo_mc_eval_capped(_p(f.data), *geo, _p(vox_key), cap, _p(totals), _p(vox_counts), _p(vox_flags), st),
+                       "tomo_mc_eval_capped")
+            _lib.check(L.tomo_mc_scan(_p(vox_counts), cap, _p(vox_voff), _p(vox_foff), None, _p(tot2), _p(ws2), wsb2, st),
+                       "tomo_mc_scan")
+            host = stats[:8].cpu()
+            na, nv, nf = int(host[0]), int(host[4]), int(host[5])
+            if na > cap:
+                COUNTERS["na_hint_miss"] = COUNTERS.get("na_hint_miss", 0) + 1
+                na = None                                   # too short: the plain path below redoes list, eval and scan
+            else:
+                COUNTERS["na_hint_hit"] = COUNTERS.get("na_hint_hit", 0) + 1
+    if na is None:
+        na = int(totals[0].item())
+        if na == 0:
+            return None
+        if na >= 2 ** 31:
+            raise _lib.TomoError("surface too large for 32-bit indices")
+        vox_key = torch.empty(na, dtype=torch.int64, device=dev)
+        _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(vox_key), st), "tomo_mc_list")
+        vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
+        vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
+        _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")
+        vox_voff = torch.empty(na + 1, dtype=torch.int32, device=dev)
+        vox_foff = torch.empty(na + 1, dtype=torch.int32, device=dev)
+        wsb2 = L.tomo_mc_scan_workspace_bytes(na)
+        ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+        _lib.check(L.tomo_mc_scan(_p(vox_counts), na, _p(vox_voff), _p(vox_foff), None, _p(tot2), _p(ws2), wsb2, st),
+                   "tomo_mc_scan")
+        nv, nf = [int(x) for x in tot2[:2].cpu()]
+    del seg_cnt
     if na == 0:
         return None
-    if na >= 2 ** 31:
-        raise _lib.TomoError("surface too large for 32-bit indices")
-    # pass 2-3: compact voxel list, one MC33 evaluation per active voxel, scan of the counts
-    vox_key = torch.empty(na, dtype=torch.int64, device=dev)
-    _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(vox_key), st), "tomo_mc_list")
-    del seg_cnt
-    vox_counts = torch.empty(na, dtype=torch.int32, device=dev)
-    vox_flags = torch.empty(na, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mc_eval(_p(f.data), *geo, _p(vox_key), na, _p(vox_counts), _p(vox_flags), st), "tomo_mc_eval")
-    vox_voff = torch.empty(na + 1, dtype=torch.int32, device=dev)
-    vox_foff = torch.empty(na + 1, dtype=torch.int32, device=dev)
-    tot2 = totals[4:]
-    wsb2 = L.tomo_mc_scan_workspace_bytes(na)
-    ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
-    _lib.check(L.tomo_mc_scan(_p(vox_counts), na, _p(vox_voff), _p(vox_foff), None, _p(tot2), _p(ws2), wsb2, st),
-               "tomo_mc_scan")
-    nv, nf = [int(x) for x in tot2[:2].cpu()]
+    _NA_HINT[hint_key] = na
     if nv == 0:
         return None
     if nv >= 2 ** 31 or nf >= 2 ** 31:
