@@ -541,7 +541,7 @@ def test_whole_path_irregular_blobs_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------ sparse field
-@pytest.mark.parametrize("case", ["ellipsoid", "blobs", "noise", "touching", "wide", "thin", "nopad"])
+@pytest.mark.parametrize("case", ["ellipsoid", "blobs", "noise", "touching", "wide", "thin", "nopad", "nopad_solid"])
 def test_sparse_field_same_mesh(dev, case):
     """tomo_field_fill_bits_sparse leaves constant tiles unwritten that no marching-cubes cell can touch.  The buffer is
     pre-filled with NaN here, so any read of an unwritten float would poison the mesh: mesh == the dense field's mesh,
@@ -564,9 +564,12 @@ def test_sparse_field_same_mesh(dev, case):
     elif case == "thin":
         v = np.zeros((5, 3, 33), bool)
         v[2, 1, 5:30] = True
+    elif case == "nopad_solid":       # no pad ring and solid up to the array's edge: reflect makes the border tiles constant
+        v = np.ones((37, 19, 95), bool)
+        v[5, 1, 7] = False
     else:
         v = np.asarray(O.ellipsoid_masks(48, 40, 24))
-    pad = case != "nopad"
+    pad = case not in ("nopad", "nopad_solid")
     vol = to_vol(v, dev)
     L = pipeline._lib.lib()
     nz, ny, nx = v.shape
@@ -582,7 +585,9 @@ def test_sparse_field_same_mesh(dev, case):
     st = torch.cuda.current_stream().cuda_stream
     assert L.tomo_field_fill_bits_sparse(vol.bits.data_ptr(), poisoned.data_ptr(), nz, ny, nx, p, sb.data_ptr(), gc.data_ptr(),
                                          span.data_ptr(), st) == 0
-    assert torch.equal(gc, fd.gcls)
+    # group classes: identical, or constant (0 / 1, no records) where the dense kernel stored records -- that one classifies a
+    # tile by a window that is not clipped to the array, so a tile at the array's edge can be "mixed" there and constant here
+    assert bool(((gc == fd.gcls) | ((gc < 2) & (fd.gcls == 2))).all())
     written = ~torch.isnan(poisoned)
     assert torch.equal(poisoned[written], fd.data[written])          # what is written is the dense field
     fs.data = poisoned
