@@ -1,0 +1,14 @@
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomography_3d_reconstructor_amd import pipeline, voxel_processor as vpm
+from oracle import oracle as O
+n = 1024
+masks = [m for m in np.asarray(O.ellipsoid_masks(n, n, n))]
+masks = [np.ascontiguousarray(m) for m in masks]            # separate arrays, like a loader's list
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d = vpm._stage_masks(masks); torch.cuda.synchronize(); t1 = time.perf_counter()
+    vol = pipeline.close_ends(pipeline.pack(d), inplace=True); torch.cuda.synchronize(); t2 = time.perf_counter()
+    h = vpm.to_host_volume(vol); t3 = time.perf_counter()
+    print("rep %d: stage+upload %.1f ms | pack+close %.1f ms | download volume %.1f ms" % (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+    del h, d, vol
