@@ -1,7 +1,7 @@
 """Ad-hoc fuzz of the whole hot path against the CPU oracle on random small volumes (close ends, smoothing, field, marching
 cubes, slice depths, unique / remap), with the size hints and -- second half of the cases -- the sparse field switched on."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run as: python tests/fuzz_path.py [seed] [cases]
 from tomography_3d_reconstructor_amd import pipeline
 from oracle import oracle as O
 dev = torch.device("cuda:0")

@@ -5,12 +5,11 @@ import contextlib, io, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tomography_3d_reconstructor_amd import SurfaceExtractor, VoxelProcessor  # noqa: E402
+from tomography_3d_reconstructor_amd import SurfaceExtractor, VoxelProcessor, pipeline  # noqa: E402
 from tomography_3d_reconstructor_amd.volume_calculator import VolumeCalculator  # noqa: E402
-from oracle import oracle as O  # noqa: E402  (only for the synthetic masks)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-masks = O.ellipsoid_masks(n, n, n)
+masks = [np.ascontiguousarray(m) for m in pipeline.ellipsoid_mask(n, n, n, torch.device('cuda:0')).cpu().numpy()]   # SURVEY 8(d) generator
 vp, se, vc = VoxelProcessor(), SurfaceExtractor(), VolumeCalculator()
 for rep in range(3):
     t = [time.perf_counter()]

@@ -1,10 +1,8 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tomography_3d_reconstructor_amd import pipeline, voxel_processor as vpm
-from oracle import oracle as O
 n = 1024
-masks = [m for m in np.asarray(O.ellipsoid_masks(n, n, n))]
-masks = [np.ascontiguousarray(m) for m in masks]            # separate arrays, like a loader's list
+masks = [np.ascontiguousarray(m) for m in pipeline.ellipsoid_mask(n, n, n, torch.device('cuda:0')).cpu().numpy()]   # separate arrays, like a loader's list
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     d = vpm._stage_masks(masks); torch.cuda.synchronize(); t1 = time.perf_counter()
