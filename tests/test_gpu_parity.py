@@ -639,3 +639,31 @@ def test_marching_cubes_size_hints(dev):
             assert torch.equal(a, b), k
     assert pipeline.COUNTERS.get("na_hint_miss", 0) - c0.get("na_hint_miss", 0) >= 1
     assert pipeline.COUNTERS.get("na_hint_hit", 0) - c0.get("na_hint_hit", 0) >= 3
+
+
+# ------------------------------------------------------------------ masks that touch the first / last slice
+@pytest.mark.parametrize("kind", ["first", "both", "noise_first"])
+def test_one_sort_unique_with_clamped_first_slice(dev, kind):
+    """A mask in the first slice puts vertices on the z edges below it; the slice-depth map clamps their z to 0 -- the z of
+    the in-plane vertices of that slice -- so np.unique interleaves two runs of the one-sort path.  The merge of those runs
+    keeps the fast path exact: same mesh as the oracle WITHOUT falling back to the general sort."""
+    rng = np.random.default_rng(3)
+    shape = (12, 40, 90)
+    if kind == "first":
+        v = np.zeros(shape, bool); v[0:5, 8:30, 10:70] = True
+    elif kind == "both":
+        v = np.zeros(shape, bool); v[:, 5:35, 20:60] = True; v[4:8, 15:20, 30:40] = False
+    else:
+        v = np.zeros(shape, bool); v[0:3] = rng.random((3,) + shape[1:]) < 0.5
+        v = O.smooth(v, 1, True); v[0] |= rng.random(shape[1:]) < 0.2
+    depths = np.linspace(0.3, 0.9, shape[0])
+    ref = O.SurfaceExtractor().extract_manifold_surface(v, depths, 0.7, 1.3)
+    c0 = dict(pipeline.COUNTERS)
+    got = pipeline.extract_surface(to_vol(v, dev), depths, 0.7, 1.3, True, True)
+    assert ref is not None and got is not None
+    gv, gf = got[0].cpu().numpy(), got[1].cpu().numpy()
+    assert gv.shape == ref[0].shape and np.array_equal(gv.view(np.int32), np.ascontiguousarray(ref[0]).view(np.int32))
+    assert np.array_equal(gf, ref[1])
+    if kind != "noise_first":                     # (noise may break the one-sort order elsewhere: float32 ties between buckets)
+        assert pipeline.COUNTERS["unique_one_sort"] - c0["unique_one_sort"] == 1
+        assert pipeline.COUNTERS["unique_fallback"] - c0["unique_fallback"] == 0

@@ -108,32 +108,72 @@ __global__ __launch_bounds__(256) void uq_heads_kernel(const float *__restrict__
 
 // head flag of sorted position i as a function object: lets the scan read the flags through a transform iterator
 // instead of an array (one kernel and 14 MB of traffic less per 3.5 M vertices)
+// Sorted order of the one-sort path: idx, except for positions [off[1], off[3]) -- the between-planes part of slab 0 and
+// the in-plane part of slab 1 -- which are read from `alt`, where uq_merge_kernel has merged those two runs (off == null:
+// plain idx).
+struct UqOrder {
+    const u32 *idx, *alt, *off;
+    __device__ u32 at(u32 i) const
+    {
+        if (off != nullptr && i >= off[1] && i < off[3]) return alt[i];
+        return idx[i];
+    }
+};
+
 struct UqHead {
     const float *vpos;
-    const u32 *idx;
+    UqOrder ord;
     __device__ u32 operator()(u32 i) const
     {
         if (i == 0) return 1u;
-        const float *a = vpos + 3 * (int64_t)idx[i], *b = vpos + 3 * (int64_t)idx[i - 1];
+        const float *a = vpos + 3 * (int64_t)ord.at(i), *b = vpos + 3 * (int64_t)ord.at(i - 1);
         return (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) ? 1u : 0u;
     }
 };
 
+// With padding, the vertices on the z edges between padded slices 0 and 1 (a mask that touches the first slice) all get
+// z' = 0 from the slice-depth map (surface_extractor.py:100-101 clamps z < 0), the same z' as the in-plane vertices of
+// slice 1: two runs, each sorted by (z', y, x), that np.unique interleaves.  One thread per element of either run finds
+// its rank in the other by binary search (ties: the first run first) -- a merge that is the identity whenever the first
+// run's z' lie below the second's, i.e. for every other pair of neighbouring buckets and without the clamp.
+__global__ __launch_bounds__(256) void uq_merge_kernel(const float *__restrict__ vpos, const u32 *__restrict__ off,
+                                                       const u32 *__restrict__ idx, u32 *__restrict__ alt)
+{
+    const u32 o1 = off[1], o2 = off[2], o3 = off[3];
+    const u32 na = o2 - o1, nb = o3 - o2;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < na + nb; t += gridDim.x * blockDim.x) {
+        const bool inA = t < na;
+        const u32 src = idx[inA ? o1 + t : o2 + (t - na)];
+        const float *k = vpos + 3 * (int64_t)src;
+        const float k0 = k[0], k1 = k[1], k2 = k[2];
+        const u32 base = inA ? o2 : o1;
+        u32 lo = 0, hi = inA ? nb : na;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            const float *m = vpos + 3 * (int64_t)idx[base + mid];
+            const bool less = m[0] < k0 || (m[0] == k0 && (m[1] < k1 || (m[1] == k1 && m[2] < k2)));
+            const bool equal = m[0] == k0 && m[1] == k1 && m[2] == k2;
+            if (less || (!inA && equal)) lo = mid + 1; else hi = mid;      // B counts the A elements <= itself
+        }
+        alt[o1 + (inA ? t : t - na) + lo] = src;
+    }
+}
+
 // scatter of the one-sort path: recomputes the head flag (same two rows the order check needs anyway), counts the places
 // where the sorted result descends lexicographically, writes uniq / rank
 __global__ __launch_bounds__(256) void uq_scatter_check_kernel(const float *__restrict__ vpos, int64_t nv,
-                                                               const u32 *__restrict__ idx, const u32 *__restrict__ hscan,
+                                                               const UqOrder ord, const u32 *__restrict__ hscan,
                                                                float *__restrict__ uniq, int32_t *__restrict__ rank,
                                                                u64 *__restrict__ totals)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
-    const u32 src = idx[i];
+    const u32 src = ord.at((u32)i);
     const float *a = vpos + 3 * (int64_t)src;
     const float a0 = a[0], a1 = a[1], a2 = a[2];
     bool head = true;
     if (i > 0) {
-        const float *b = vpos + 3 * (int64_t)idx[i - 1];
+        const float *b = vpos + 3 * (int64_t)ord.at((u32)i - 1u);
         const float b0 = b[0], b1 = b[1], b2 = b[2];
         head = (a0 != b0 || a1 != b1 || a2 != b2);
         if (a0 < b0 || (a0 == b0 && (a1 < b1 || (a1 == b1 && a2 < b2)))) atomicAdd(&totals[2], 1ull);
@@ -334,6 +374,7 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     size_t tb = L.temp_bytes;
     hipStream_t s = (hipStream_t)stream;
     unsigned blocks = (unsigned)ceil_div64(nv, 256);
+    UqOrder order{(const u32 *)idx_c, nullptr, nullptr};
     static const bool global_sort = getenv("TOMO_UQ_GLOBAL_SORT") != nullptr;     // A/B switch: one 48-bit device-wide sort
     if (global_sort || Nz <= 0 || Nz > UQ_MAX_SLABS) {
         hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny,
@@ -363,11 +404,16 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
             e = rocprim::segmented_radix_sort_pairs<UqSegCfg>(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
                                                               (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s);
         if (e != hipSuccess) return TOMO_E_LAUNCH;
+        if (Nz >= 2) {                              // the clamped run of slab 0 and the plane of slab 1 (see uq_merge_kernel)
+            hipLaunchKernelGGL(uq_merge_kernel, dim3(256), dim3(256), 0, s, vpos, (const u32 *)offsets, (const u32 *)idx_c, idx_b);
+            order.alt = idx_b;
+            order.off = offsets;
+        }
     }
     tb = L.temp_bytes;
-    auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{vpos, (const u32 *)idx_c});
+    auto heads = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u32>(0u), UqHead{vpos, order});
     if (rocprim::inclusive_scan(temp, tb, heads, hscan, (size_t)nv, rocprim::plus<u32>(), s) != hipSuccess) return TOMO_E_LAUNCH;
-    hipLaunchKernelGGL(uq_scatter_check_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, (const u32 *)idx_c, (const u32 *)hscan,
+    hipLaunchKernelGGL(uq_scatter_check_kernel, dim3(blocks), dim3(256), 0, s, vpos, nv, order, (const u32 *)hscan,
                        uniq, rank, (u64 *)totals);
     return tomo_status();
 }
