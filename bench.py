@@ -1,45 +1,64 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path (mask stack -> field -> marching cubes -> final mesh).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload default|cfg3|cfg4|cfg5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one pass of the whole hot path over one synthetic ellipsoid mask stack that is already
-resident in HBM (uint8, 1 B/voxel): pack -> close ends -> opening + 3 closings -> field ("SDF") fill ->
-Lewiner marching cubes (count/scan/emit) -> vertex finalisation -> unique/remap.  Outputs stay in HBM.
-N = 1: the 1024^3 ellipsoid of BASELINE.json (configs[2]).  N > 1: Z-slab sharding, 1024 slices per rank
-(weak scaling), one-slice field halo and bit-volume halos over RCCL (tomography_3d_reconstructor_amd/slab.py).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself (a fresh
+`python -m torch.distributed.run` child, BEFORE this process touches the GPU; the parent only relays the child's
+output and exit code).  Under torch.distributed.run `--gpus` must equal WORLD_SIZE or the run refuses to start.
+
+One "step" = one pass of the whole hot path over one synthetic ellipsoid mask stack that is already resident in HBM
+(uint8, 1 B/voxel): pack -> close ends -> opening + 3 closings -> field ("SDF") fill -> Lewiner marching cubes
+(classify/scan/list/eval/emit) -> vertex finalisation -> unique/remap.  Outputs stay in HBM.
+
+Workloads (BASELINE.json configs; sizes are width x height x slices there, (nz, ny, nx) here):
+  default  N = 1: cfg3 = the 1024^3 ellipsoid.  N > 1: Z-slabs of 1024 slices of 1024^2 per rank (WEAK scaling:
+           the N = 1 point is the BENCH line), halos over RCCL (tomography_3d_reconstructor_amd/slab.py).
+  cfg3     (1024, 1024, 1024) total      cfg4  (2048, 1024, 1024) total      cfg5  (4096, 2048, 2048) total
+           -- a FIXED total volume cut into N Z-slabs (STRONG scaling; N = 1 runs the whole stack on one GPU).
 
 Prints ONE JSON line (rank 0) with metric/value/unit..., plus
-  roofline:      the field ("SDF") kernel, algorithmic 5 B per padded voxel / measured kernel time (HIP events
-                 on the launch stream, inside the timed region) vs the 8 TB/s HBM3E peak;
-  cpu_baseline:  the CPU oracle (a C/NumPy restatement of the reference, single thread) on a bounded sample.
+  roofline:      the field ("SDF") kernel: `achieved`/`frac` = algorithmic 5 B per padded voxel / measured kernel time
+                 (HIP events on the launch stream, inside the timed region) vs the 8 TB/s HBM3E peak; `frac_traffic` =
+                 the same with the bytes the kernel actually moves (rocprofv3 counters, separate passes; the kernel
+                 reads the bit-packed volume, not the 1 B/voxel mask -- that is read by pack16_kernel);
+  pass_floor:    the whole pass against its own HBM floor (1 B mask in + 4 B field out per voxel);
+  cold_pass_ms, host_to_host_ms: one pass without the size hints of earlier passes; the three drop-in class methods
+                 host list in -> host arrays out (PCIe inclusive) -- reported beside `value`, never as `value`;
+  cpu_baseline:  the CPU oracle (a C/NumPy restatement of the reference, single thread) on a bounded sample;
+  comm (N > 1):  ranks / distinct devices seen by the process group, halo bytes and time per pass.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from tomography_3d_reconstructor_amd import _lib, pipeline  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0
+WORKLOADS = {"cfg3": (1024, 1024, 1024), "cfg4": (2048, 1024, 1024), "cfg5": (4096, 2048, 2048)}
+CONFIG_INDEX = {"cfg3": 2, "cfg4": 3, "cfg5": 4}
+FIELD_PMC = os.path.join("profiles", "r02_field_pmc.json")      # written by tools/profile_round.sh (rocprofv3 --pmc passes)
+FIELD_PMC_OLD = os.path.join("profiles", "r01_field_pmc.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS),
+                    help="default: 1024^3 per rank (weak); cfg3/cfg4/cfg5: BASELINE configs[2..4], total volume fixed (strong)")
     ap.add_argument("--size", type=int, nargs=3, default=None, metavar=("NZ", "NY", "NX"),
-                    help="per-rank volume (default 1024 1024 1024)")
+                    help="per-rank volume instead of 1024 1024 1024 (weak), or the TOTAL volume with --strong")
+    ap.add_argument("--strong", action="store_true", help="--size is the total volume, cut into --gpus Z-slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip cold_pass_ms / host_to_host_ms (N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1; gloo (halos staged through the host) only to rehearse the "
                          "multi-rank code path with several ranks on ONE GPU -- never a measurement")
@@ -47,20 +66,60 @@ def parse():
                     help="opt-in: do not materialise the parts of the float field that marching cubes cannot read "
                          "(same mesh; NOT the headline configuration -- the roofline entry then only carries a note)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the cube the CPU oracle is timed on")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-launched run (0: pick a free one)")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------- launch decision (no GPU, no torch)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_plan(args, env, argv):
+    """What this process has to do, decided before anything touches the GPU:
+      ("run", world)        -- be a rank (world = 1: the plain single-GPU run)
+      ("spawn", command)    -- --gpus N > 1 outside torch.distributed.run: start the N ranks as a child process
+      ("refuse", message)   -- --gpus disagrees with the WORLD_SIZE this process was launched with"""
+    world = env.get("WORLD_SIZE")
+    if world is None:
+        if args.gpus <= 1:
+            return ("run", 1)
+        port = args.master_port or _free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        return ("spawn", cmd)
+    world = int(world)
+    if args.gpus != world:
+        return ("refuse", "bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus "
+                          "(or run `python bench.py --gpus N` without torch.distributed.run)" % (args.gpus, world))
+    return ("run", world)
+
+
+def workload_shape(args, world):
+    """-> (total (gz, ny, nx), scaling, name)."""
+    if args.workload != "default":
+        gz, ny, nx = WORKLOADS[args.workload]
+        return (gz, ny, nx), "strong", args.workload
+    if args.size and args.strong:
+        gz, ny, nx = args.size
+        return (gz, ny, nx), "strong", "custom"
+    nz, ny, nx = args.size if args.size else (1024, 1024, 1024)
+    return (nz * world, ny, nx), "weak", ("custom" if args.size else ("cfg3" if world == 1 else "cfg3-per-rank"))
+
+
+# ----------------------------------------------------------------------------- the measured run
 class FieldTimer:
-    """HIP events around every field-kernel launch (tomo_field_fill / tomo_field_fill_bits; torch events on the launch stream)."""
+    """HIP events around every field-kernel launch (tomo_field_fill*; torch events on the launch stream)."""
 
-    def __init__(self):
+    def __init__(self, torch, lib):
         self.pairs = []
         self.padded_voxels = 0
         self.enabled = False
-        self._orig = None
-
-    def install(self):
-        L = _lib.lib()
+        self.torch = torch
         timer = self
 
         def wrap(orig):
@@ -78,22 +137,15 @@ class FieldTimer:
                 return rc
             return wrapped
 
-        # ctypes function objects are attributes of the CDLL instance; both entry points launch the field kernel
-        L.tomo_field_fill = wrap(L.tomo_field_fill)
-        L.tomo_field_fill_bits = wrap(L.tomo_field_fill_bits)
-        L.tomo_field_fill_bits_sparse = wrap(L.tomo_field_fill_bits_sparse)
+        # ctypes function objects are attributes of the CDLL instance; all three entry points launch the field kernel
+        lib.tomo_field_fill = wrap(lib.tomo_field_fill)
+        lib.tomo_field_fill_bits = wrap(lib.tomo_field_fill_bits)
+        lib.tomo_field_fill_bits_sparse = wrap(lib.tomo_field_fill_bits_sparse)
 
     def mean_ms(self):
         if not self.pairs:
             return None
-        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs]))
-
-
-def one_pass(mask, depths):
-    vol = pipeline.pack(mask)
-    vol = pipeline.close_ends(vol, inplace=True)       # the packed copy is this pass's own
-    vol = pipeline.smooth(vol, 3, True)
-    return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
+        return float(sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs))
 
 
 def cpu_baseline(n):
@@ -112,50 +164,98 @@ def cpu_baseline(n):
             "n_vertices": int(len(res[0])), "n_faces": int(len(res[1]))}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def host_to_host(mask_dev, nz):
+    """SURVEY 8(d)'s metric as written: the three drop-in class methods, host list of 2-D bool masks in -> host
+    (vertices, faces) out (upload, the 1 B/voxel volume downloads and the mesh download included)."""
+    import contextlib
+    import io
+    from tomography_3d_reconstructor_amd import SurfaceExtractor, VoxelProcessor
+    stack = mask_dev.cpu().numpy().view(bool)
+    masks = [stack[i].copy() for i in range(nz)]          # separate pageable arrays, as an image loader produces them
+    del stack
+    times = []
+    shape = None
+    for _ in range(2):                                    # the first run grows the page-locked staging pools
+        vp, se = VoxelProcessor(), SurfaceExtractor()
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            vol = vp.create_voxel_data(masks, True, 0, nz, 0)
+            depths = vp.calculate_slice_depths(float(nz))
+            sm = vp.smooth_voxel_data(vol, iterations=3, create_manifold=True)
+            res = se.extract_manifold_surface(sm, depths, 1.0, 1.0, smooth=True, manifold=True, add_padding=True)
+            times.append((time.perf_counter() - t0) * 1e3)
+        shape = (len(res[0]), len(res[1])) if res is not None else None
+        del vol, sm, res
+    return times, shape
+
+
+def run(args, world):
+    import datetime
+    import numpy as np
+    import torch
+    from tomography_3d_reconstructor_amd import _lib, pipeline
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
     if args.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)        # rehearsal: ranks may share a GPU
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        print("bench.py: rank %d needs GPU %d, %d visible" % (rank, local, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    td = None
+    comm_info = None
     if dist:
         import torch.distributed as td
+        tmo = datetime.timedelta(seconds=120)          # a mismatched exchange fails after two minutes instead of hanging
         if args.backend == "nccl":
-            td.init_process_group("nccl", device_id=dev)
+            td.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            td.init_process_group("gloo")
-    nz, ny, nx = args.size if args.size else (1024, 1024, 1024)
+            td.init_process_group("gloo", timeout=tmo)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions of this script live
 
-    timer = FieldTimer()
-    timer.install()
+    (gz, ny, nx), scaling, wname = workload_shape(args, world)
+    timer = FieldTimer(torch, _lib.lib())
     if args.sparse_field:
         pipeline.FIELD_SPARSE = True
 
+    job = comm = None
     if dist:
         from tomography_3d_reconstructor_amd import slab
-        gz = nz * world
-        job = slab.SlabJob(gz, ny, nx, slab.TorchDistComm(dev))
+        comm = slab.TorchDistComm(dev)
+        try:
+            comm_info = slab.preflight(comm)           # one neighbour exchange + one all-gather; who is on which device
+        except Exception as e:                         # noqa: BLE001 -- any transport failure: say so and stop, do not hang
+            print("bench.py: rank %d: RCCL preflight failed: %r" % (rank, e), file=sys.stderr, flush=True)
+            sys.exit(3)
+        if args.backend == "nccl" and comm_info["distinct_devices"] != world:
+            print("bench.py: %d ranks on %d distinct devices" % (world, comm_info["distinct_devices"]), file=sys.stderr)
+            sys.exit(3)
+        job = slab.SlabJob(gz, ny, nx, comm)
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
         depths = np.full(gz, 1.0)
 
         def step():
             return job.run(mask, depths, 1.0, 1.0)
-        total_voxels = gz * ny * nx
-        workload = "%dx%dx%d ellipsoid stack, Z-slabs of %d slices over %d GPUs (halos over RCCL)" % (nx, ny, gz, nz, world)
         parallelism = "zslab%d" % world + ("" if args.backend == "nccl" else " (REHEARSAL over gloo, not a measurement)")
+        workload = "%dx%dx%d ellipsoid stack, %d Z-slabs of %d slices (halos over %s)" % (
+            nx, ny, gz, world, job.z1 - job.z0, "RCCL" if args.backend == "nccl" else "gloo")
     else:
-        mask = pipeline.ellipsoid_mask(nz, ny, nx, dev).view(torch.uint8)
-        depths = np.full(nz, 1.0)
+        mask = pipeline.ellipsoid_mask(gz, ny, nx, dev).view(torch.uint8)
+        depths = np.full(gz, 1.0)
 
         def step():
-            return one_pass(mask, depths)
-        total_voxels = nz * ny * nx
-        workload = "%dx%dx%d ellipsoid stack%s" % (nx, ny, nz, " (BASELINE configs[2])" if (nz, ny, nx) == (1024, 1024, 1024) else "")
+            vol = pipeline.pack(mask)
+            vol = pipeline.close_ends(vol, inplace=True)       # the packed copy is this pass's own
+            vol = pipeline.smooth(vol, 3, True)
+            return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
         parallelism = "single"
+        workload = "%dx%dx%d ellipsoid stack" % (nx, ny, gz)
+    if wname in CONFIG_INDEX and (gz, ny, nx) == WORKLOADS[wname]:
+        workload += " (BASELINE configs[%d])" % CONFIG_INDEX[wname]
+    total_voxels = gz * ny * nx
 
     def barrier():
         torch.cuda.synchronize()
@@ -168,6 +268,8 @@ def main():
         res = step()
     for _ in range(args.warmup):
         res = step()
+    if comm is not None:
+        comm.reset_stats()
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
@@ -176,26 +278,32 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions of this script live
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
 
-    ms = dt / max(args.steps, 1) * 1e3
+    steps = max(args.steps, 1)
+    ms = dt / steps * 1e3
     value = total_voxels * args.steps / dt / 1e6
     fms = timer.mean_ms()
     roofline = None
     if fms:
         alg = 5.0 * timer.padded_voxels              # 1 B mask + 4 B field per padded voxel of the launch (rank 0)
         ach = alg / (fms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_field_pmc.json")   # written by tools/profile_round.sh
-        if not dist and os.path.exists(pmc) and (nz, ny, nx) == (1024, 1024, 1024):
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]   # separate rocprofv3 --pmc passes of this command
         roofline = {"bound": "hbm", "kernel": "field_tile_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes": alg, "kernel_ms": round(fms, 4)}
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes": alg, "kernel_ms": round(fms, 4),
+                    "note": "achieved/frac: SURVEY 8(d)'s 5 B per padded voxel (1 B mask + 4 B f32) / kernel time. The kernel itself "
+                            "reads the bit-packed volume (1/8 B per voxel); the 1 B/voxel mask is read by pack16_kernel. "
+                            "frac_traffic prices the kernel by the bytes it moves."}
+        pmc = next((p for p in (FIELD_PMC, FIELD_PMC_OLD) if os.path.exists(os.path.join(ROOT, p))), None)
+        if not dist and pmc and (gz, ny, nx) == (1024, 1024, 1024) and not args.sparse_field:
+            traffic = json.load(open(os.path.join(ROOT, pmc)))["hbm_bytes_per_launch"]
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % pmc
+            roofline["achieved_traffic"] = round(traffic / (fms * 1e-3) / 1e9, 1)
+            roofline["frac_traffic"] = round(traffic / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if args.sparse_field and not dist:
             # the dense figure does not describe this run: most of the field is never written
             roofline = {"bound": "hbm", "kernel": "field_span/comb/worklist/tile kernels (tile-sparse fill)", "achieved": None,
@@ -204,20 +312,58 @@ def main():
                         "note": "opt-in sparse field: ~7 % of the tiles are written; the dense 5 B/voxel figure does not apply"}
     nverts = int(res[0].shape[0]) if res else 0
     nfaces = int(res[1].shape[0]) if res else 0
+    comm_out = None
     if dist:
         cnt = torch.tensor([nverts, nfaces], dtype=torch.int64, device=rdev)
         td.all_reduce(cnt)
         nverts, nfaces = [int(x) for x in cnt.cpu()]
+        st = comm.stats
+        agg = torch.tensor([st["bytes_sent"], st["calls"]], dtype=torch.float64, device=rdev)
+        td.all_reduce(agg)
+        mx = torch.tensor([st["seconds"], st["bytes_sent"]], dtype=torch.float64, device=rdev)
+        td.all_reduce(mx, op=td.ReduceOp.MAX)
+        comm_out = dict(comm_info)
+        comm_out.update({
+            "halo_bytes_per_pass_all_ranks": int(agg[0].item() / steps), "halo_bytes_per_pass_max_rank": int(mx[1].item() / steps),
+            "comm_calls_per_pass_per_rank": round(agg[1].item() / steps / world, 1),
+            "comm_ms_per_pass_max_rank": round(mx[0].item() / steps * 1e3, 3),
+            "comm_ms_note": "host wall time inside exchange/all_gather calls, includes waiting for the kernels that produce the halos"})
+    pass_floor_bytes = 5.0 * total_voxels            # 1 B mask in + 4 B f32 field out per voxel: what a pass cannot avoid moving
     out = {
         "metric": "Mvoxels/s (SDF+MC) on 1024^3 ellipsoid stack; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload, "parallelism": parallelism, "inputs": "uint8 mask stack resident in HBM",
+        "config": {"workload": workload, "workload_id": wname, "parallelism": parallelism,
+                   "inputs": "uint8 mask stack resident in HBM", "outputs": "final (vertices, faces) resident in HBM",
                    "field": "tile-sparse (opt-in)" if pipeline.FIELD_SPARSE else "dense",
                    "n_vertices": nverts, "n_faces": nfaces},
         "roofline": roofline,
+        "pass_floor": {"bytes": pass_floor_bytes, "frac": round(pass_floor_bytes / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "whole pass vs its own HBM floor (1 B mask in + 4 B field out per voxel) per GPU at 8 TB/s"},
     }
+    if comm_out is not None:
+        out["comm"] = comm_out
+    if not dist and not args.no_extras:
+        del res
+        pipeline._NA_HINT.clear()
+        for k in pipeline.COUNTERS:
+            pipeline.COUNTERS[k] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = step()
+        torch.cuda.synchronize()
+        out["cold_pass_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        out["cold_pass_note"] = "one pass with the marching-cubes size hints and path counters cleared (allocator warm)"
+        del r
+        if total_voxels <= 2 ** 31:
+            times, shape = host_to_host(mask, gz)
+            out["host_to_host_ms"] = round(min(times), 2)
+            out["host_to_host_runs_ms"] = [round(x, 2) for x in times]
+            out["host_to_host_mvoxels_s"] = round(total_voxels / (min(times) * 1e-3) / 1e6, 1)
+            out["host_to_host_note"] = ("create_voxel_data + smooth_voxel_data + extract_manifold_surface of the drop-in classes, "
+                                        "host list of masks in -> host arrays out (PCIe inclusive), same volume; SURVEY 8(d)'s "
+                                        "end-to-end metric; never `value`; mesh %s" % (shape,))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
@@ -226,5 +372,22 @@ def main():
         td.destroy_process_group()
 
 
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    plan = launch_plan(args, os.environ, argv)
+    if plan[0] == "refuse":
+        print(plan[1], file=sys.stderr)
+        return 2
+    if plan[0] == "spawn":
+        # this process has not touched the GPU (no torch import yet): start the ranks as a child and hand its code on
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        return subprocess.call(plan[1], env=env)
+    run(args, plan[1])
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

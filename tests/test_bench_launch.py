@@ -1,0 +1,60 @@
+"""CPU tier: bench.py's launch decision (taken before anything touches the GPU) and its workload table."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (imports neither torch nor the HIP library at module level)
+
+
+def test_bench_module_import_is_gpu_free():
+    code = "import sys; sys.path.insert(0, %r); import bench; assert 'torch' not in sys.modules, 'bench imported torch'" % ROOT
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0
+
+
+def test_single_gpu_runs_in_process():
+    argv = ["--steps", "5"]
+    assert bench.launch_plan(bench.parse(argv), {}, argv) == ("run", 1)
+
+
+def test_gpus_n_without_world_size_spawns_n_ranks():
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2", "--workload", "cfg5"]
+    kind, cmd = bench.launch_plan(bench.parse(argv), {}, argv)
+    assert kind == "spawn"
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                      # the ranks get this command line unchanged
+
+
+def test_under_torchrun_be_a_rank_or_refuse():
+    argv = ["--gpus", "4"]
+    assert bench.launch_plan(bench.parse(argv), {"WORLD_SIZE": "4", "RANK": "1"}, argv) == ("run", 4)
+    kind, msg = bench.launch_plan(bench.parse(argv), {"WORLD_SIZE": "2"}, argv)
+    assert kind == "refuse" and "--gpus 4" in msg and "WORLD_SIZE=2" in msg
+    # --gpus 1 (the default) under a multi-rank launch is a mistake too, not a silent single-GPU run
+    assert bench.launch_plan(bench.parse([]), {"WORLD_SIZE": "8"}, [])[0] == "refuse"
+
+
+def test_refusal_exit_code(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert bench.main(["--gpus", "8"]) == 2
+
+
+@pytest.mark.parametrize("argv,world,total,scaling", [
+    ([], 1, (1024, 1024, 1024), "weak"),
+    ([], 8, (8192, 1024, 1024), "weak"),
+    (["--workload", "cfg4"], 2, (2048, 1024, 1024), "strong"),
+    (["--workload", "cfg4"], 4, (2048, 1024, 1024), "strong"),
+    (["--workload", "cfg5"], 8, (4096, 2048, 2048), "strong"),
+    (["--size", "256", "512", "512"], 2, (512, 512, 512), "weak"),
+    (["--size", "256", "512", "512", "--strong"], 2, (256, 512, 512), "strong"),
+])
+def test_workloads(argv, world, total, scaling):
+    shape, sc, _ = bench.workload_shape(bench.parse(argv), world)
+    assert shape == total and sc == scaling

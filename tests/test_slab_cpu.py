@@ -91,8 +91,12 @@ def _gloo_worker(rank, world, port, shape, seed, tmpdir):
         v = make_volume(seed, shape)
         depths = np.full(shape[0], 0.5)
         comm = slab.TorchDistComm(torch.device("cpu"))
+        info = slab.preflight(comm)                  # bench.py's first contact: one exchange + one all-gather
+        assert info["ranks"] == world and info["backend"] == "gloo"
+        comm.reset_stats()
         out = {}
         run_rank(comm, v, depths, 1.0, 1.0, out)
+        assert comm.stats["calls"] > 0 and comm.stats["bytes_sent"] > 0
         np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), v=out[rank][0], f=out[rank][1], off=out[rank][2],
                  nvg=out[rank][3])
     finally:

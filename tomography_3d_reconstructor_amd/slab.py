@@ -17,7 +17,7 @@ cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, a
                gives the global numbering.  Faces stay on their rank, in reference order.
 
 The result is bit-identical to the single-GPU path (tests/test_slab_cpu.py with the CPU oracle as engine over
-gloo, tests/test_gpu_parity.py::test_slab_two_ranks_one_gpu with the HIP engine).
+gloo, tests/test_gpu_parity.py::test_slab_ranks_on_one_gpu_match_single_gpu with the HIP engine).
 
 The class is written against two small interfaces so that the same orchestration code runs on RCCL, on gloo
 (CPU tests) and inside one process (two threads sharing one GPU):
@@ -45,6 +45,12 @@ class TorchDistComm:
         # gloo moves host memory only: device tensors are staged through the host then (a rehearsal path -- several ranks
         # sharing one GPU, where RCCL refuses to start; the product path is "nccl" = RCCL with device buffers end to end)
         self.stage_host = td.get_backend() == "gloo" and torch.device(device).type != "cpu"
+        self.reset_stats()
+
+    def reset_stats(self):
+        """bytes_sent: payload this rank handed to send / all_gather; seconds: host wall time inside the calls (it
+        includes waiting for the kernels that produce what is sent -- the streams are only joined here)."""
+        self.stats = {"bytes_sent": 0, "calls": 0, "seconds": 0.0}
 
     @staticmethod
     def _bytes(t):
@@ -58,6 +64,8 @@ class TorchDistComm:
         unless recv_shape_prev / recv_shape_next say otherwise (variable-size lists: exchange the counts first).
         All sends and receives of one call go out as ONE batch (a grouped RCCL call: both directions at once, no
         send/recv ordering to deadlock on); empty tensors are skipped on both sides."""
+        import time
+        t_in = time.perf_counter()
         td = self.td
         r, w = self.rank, self.world
         ops, keep = [], []
@@ -95,17 +103,58 @@ class TorchDistComm:
         elif ops:
             for q in td.batch_isend_irecv(ops):
                 q.wait()
+        self.stats["bytes_sent"] += sum(k.numel() * k.element_size() for k in keep)
+        self.stats["calls"] += 1
+        self.stats["seconds"] += time.perf_counter() - t_in
         return from_prev, from_next
 
     def all_gather(self, t):
+        import time
+        t_in = time.perf_counter()
         if self.stage_host:
             h = t.contiguous().cpu()
             out = [torch.empty_like(h) for _ in range(self.world)]
             self.td.all_gather(out, h)
-            return [o.to(self.device) for o in out]
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        self.td.all_gather(out, t.contiguous())
+            out = [o.to(self.device) for o in out]
+        else:
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            self.td.all_gather(out, t.contiguous())
+        self.stats["bytes_sent"] += t.numel() * t.element_size()
+        self.stats["calls"] += 1
+        self.stats["seconds"] += time.perf_counter() - t_in
         return out
+
+
+def preflight(comm):
+    """First contact of the ranks, before any volume-sized work: ONE neighbour exchange (both directions, the byte-view
+    send/recv batch the job uses) and ONE all-gather, checked for content; raises on any mismatch (a transport that
+    cannot do these must fail here, inside the process group's timeout, not in the middle of a pass).
+    -> {"ranks", "distinct_devices", "devices"} as the process group sees them."""
+    dev = comm.device
+    r, w = comm.rank, comm.world
+    probe = torch.arange(8, dtype=torch.int64, device=dev) + 1000 * r
+    lo, hi = comm.exchange(probe, probe + 1, torch.int64)
+    if r > 0 and (lo is None or not torch.equal(lo.cpu(), torch.arange(8, dtype=torch.int64) + 1000 * (r - 1) + 1)):
+        raise RuntimeError("preflight: rank %d received a wrong halo from rank %d" % (r, r - 1))
+    if r + 1 < w and (hi is None or not torch.equal(hi.cpu(), torch.arange(8, dtype=torch.int64) + 1000 * (r + 1))):
+        raise RuntimeError("preflight: rank %d received a wrong halo from rank %d" % (r, r + 1))
+    ident = [r, -1, 0, 0]
+    if torch.device(dev).type == "cuda":
+        idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        u = getattr(props, "uuid", None)
+        ub = getattr(u, "bytes", None) if u is not None else None
+        if ub is not None and len(ub) == 16:
+            ident = [r, idx, int.from_bytes(ub[:7], "little"), int.from_bytes(ub[8:15], "little")]
+        else:
+            ident = [r, idx, int(getattr(props, "pci_bus_id", idx)), int(getattr(props, "pci_domain_id", 0))]
+    got = comm.all_gather(torch.tensor(ident, dtype=torch.int64, device=dev))
+    rows = [[int(x) for x in g.cpu()] for g in got]
+    if [row[0] for row in rows] != list(range(w)):
+        raise RuntimeError("preflight: all_gather returned ranks %r" % ([row[0] for row in rows],))
+    devices = [tuple(row[1:]) for row in rows]
+    return {"ranks": w, "distinct_devices": len(set(devices)), "devices": [d[0] for d in devices],
+            "backend": comm.td.get_backend() if hasattr(comm, "td") else "threads"}
 
 
 class ThreadComm:
@@ -265,10 +314,6 @@ def slab_range(gz, rank, world):
     base, rem = divmod(gz, world)
     z0 = rank * base + min(rank, rem)
     return z0, z0 + base + (1 if rank < rem else 0)
-
-
-def _fold_words(a, b, op):
-    return op(a, b)
 
 
 class SlabJob:
