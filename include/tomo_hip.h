@@ -44,6 +44,11 @@ int tomo_host_mc_cell(const float *h_v, double iso, int8_t *h_tris, int *h_uses_
 double tomo_host_mc_edge_offset(double va, double vb);        /* vertex offset along an edge, same code */
 void tomo_host_mc_centre_offset(const double *h_v8, double *h_out3); /* (x,y,z) offset of the centre vertex */
 
+/* Full-content, position-dependent 128-bit checksum of a HOST buffer on `nthreads` host threads (h_out[0..1]).  The
+ * device-volume cache of the drop-in classes uses it to make sure a host array the caller could write to still holds
+ * what was uploaded (voxel_processor.py:84 / surface_extractor.py:43-46 read the array they are handed). */
+int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_t *h_out);
+
 /* ---------------------------------------------------------------- geometry helpers (host, pure) */
 int64_t tomo_words_per_row(int nx);                      /* ceil(nx / 64) */
 /* Extended ("halo") bit volume the field kernel reads: reflect/zero borders materialised. */

@@ -73,18 +73,65 @@ def test_product_never_imports_the_oracle():
                     assert not bad.search(text), "product file references the oracle: " + os.path.join(dirpath, f)
 
 
-def test_devcache_fingerprint_handles_large_and_small_arrays():
-    """The device-side cache key of a host volume (identity + sampled checksum): any size, edits noticed."""
+def test_host_checksum_sees_every_byte():
+    """tomo_host_checksum: full content, position dependent, the same for any thread count."""
     import numpy as np
     from tomography_3d_reconstructor_amd import _devcache
-    for shape in [(2, 3, 5), (64, 128, 128), (7, 333, 129)]:
-        a = np.zeros(shape, bool)
-        f0 = _devcache._fingerprint(a)
-        a.reshape(-1)[0] = True
-        assert _devcache._fingerprint(a) != f0
+    rng = np.random.default_rng(5)
+    for shape in [(2, 3, 5), (64, 128, 128), (7, 333, 129), (130, 100, 100)]:
+        a = rng.random(shape) < 0.5
+        h0 = _devcache.checksum(a)
+        assert h0 == _devcache.checksum(a, 1) == _devcache.checksum(a, 3) == _devcache.checksum(a.copy(), 8)
+        for off in rng.integers(0, a.size, 24):                  # any single voxel, wherever it sits
+            a.reshape(-1)[off] ^= True
+            assert _devcache.checksum(a) != h0
+            a.reshape(-1)[off] ^= True
+        assert _devcache.checksum(a) == h0
+    a = rng.random((40, 64, 64)) < 0.5
+    h0 = _devcache.checksum(a)
+    b = a.copy()
+    b[0, 0, 0:8], b[0, 0, 8:16] = a[0, 0, 8:16].copy(), a[0, 0, 0:8].copy()      # two words swapped
+    assert (b != a).any() and _devcache.checksum(b) != h0
+    assert _devcache.checksum(np.ascontiguousarray(a[:, :, ::-1])) != h0             # same bytes, other places
+    assert _devcache.checksum(np.ascontiguousarray(np.roll(a, 1))) != h0
+    assert _devcache.checksum(np.zeros(0, bool)) == _devcache.checksum(np.zeros((0, 4), bool))
+
+
+def test_devcache_never_returns_a_stale_volume(monkeypatch):
+    """A cached device copy is used only for an array that is write-protected or verified byte for byte."""
+    import numpy as np
+    from tomography_3d_reconstructor_amd import _devcache
+    _devcache.clear()
     v = object()
-    big = np.ones((70, 100, 100), bool)
+    # (1) hand-outs are write-protected: trusted while protected, dropped once the caller made them writeable
+    big = np.ones((128, 128, 128), bool)
     _devcache.put(big, v)
-    assert _devcache.get(big) is v
-    big[:] = False
+    assert not big.flags.writeable and _devcache.get(big) is v
+    try:
+        big[64, 64, 65] = False
+        raise AssertionError("a protected hand-out accepted a write")
+    except ValueError:
+        pass
+    big.flags.writeable = True                                 # (a NumPy-owned array can be unprotected; a page-locked result cannot)
+    big[64, 64, 65] = False                                    # the advisor's single-voxel edit
     assert _devcache.get(big) is None
+    # (2) a caller-owned (writeable) array: verified in full at every lookup
+    mine = np.ones((128, 128, 128), bool)
+    _devcache.put(mine, v, protect=False)
+    assert mine.flags.writeable and _devcache.get(mine) is v and _devcache.get(mine) is v
+    mine[:, :, 1::32] ^= True                                  # the advisor's strided edit (missed by a sampled checksum)
+    assert _devcache.get(mine) is None
+    mine2 = np.ones((70, 100, 100), bool)
+    _devcache.put(mine2, v, protect=False)
+    mine2.reshape(-1)[12345] = False
+    assert _devcache.get(mine2) is None
+    # (3) TOMO_WRITEABLE_RESULTS: results stay writeable like the reference's, every lookup verifies
+    monkeypatch.setattr(_devcache, "WRITEABLE_RESULTS", True)
+    res = np.zeros((128, 128, 128), bool)
+    _devcache.put(res, v)
+    assert res.flags.writeable and _devcache.get(res) is v
+    res[5, 6, 7] = True
+    assert _devcache.get(res) is None
+    # (4) a different object with the same content is not the cached one
+    assert _devcache.get(np.ones((128, 128, 128), bool)) is None
+    _devcache.clear()

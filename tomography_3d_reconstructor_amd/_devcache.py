@@ -1,38 +1,66 @@
 """Device-side cache of volumes that crossed the NumPy boundary.
 
-The reference's orchestrator hands the arrays returned by VoxelProcessor straight back into
-smooth_voxel_data / extract_manifold_surface (tomography_3d_reconstruction.py:108-134).  To avoid a
-host->device round trip per call, the bit-packed device copy is remembered against the returned
-ndarray: object identity + data pointer + shape + a sampled checksum (so an in-place edit by the caller
-is noticed and the volume is simply uploaded again).
+The reference's orchestrator hands the arrays returned by VoxelProcessor straight back into smooth_voxel_data /
+extract_manifold_surface (tomography_3d_reconstruction.py:108-134).  To avoid a host->device round trip per call the
+bit-packed device copy is remembered against the returned ndarray.  The reference always reads the array it is handed
+(voxel_processor.py:84, surface_extractor.py:43-46), so a cached copy is used ONLY when the array provably still holds
+what was uploaded:
+
+  * arrays this package returns are handed out READ-ONLY (`flags.writeable = False`; nothing in the reference writes
+    into a volume it got back -- its consumers only read).  While the flag is still clear the content cannot have been
+    changed through the array or any view of it: the cached copy is exact, at no cost.
+  * an array that is writeable at lookup (the caller set the flag, or TOMO_WRITEABLE_RESULTS=1 asks for writeable
+    results like the reference's) may have been edited: every byte is checked -- a position-dependent 128-bit checksum
+    over the whole array (native, threaded: tomo_host_checksum) against the one taken when the device copy was made --
+    and any difference, or no stored checksum, drops the entry and the array is uploaded again.
+
+There is no sampling anywhere: a hit is either write-protected or fully verified.
 """
+import ctypes
+import os
 import weakref
 from collections import OrderedDict
 
 import numpy as np
 
+from . import _lib
+
 _MAX = 4
 _cache = OrderedDict()
+WRITEABLE_RESULTS = os.environ.get("TOMO_WRITEABLE_RESULTS", "0") not in ("", "0")
+STATS = {"hit_readonly": 0, "hit_verified": 0, "miss_edited": 0, "miss_unverifiable": 0}
 
 
-def _fingerprint(arr):
-    a = np.ascontiguousarray(arr) if not arr.flags.c_contiguous else arr
-    flat = a.reshape(-1).view(np.uint8)
-    n = flat.size
-    step = max(1, n // 65536)
-    sample = np.ascontiguousarray(flat[::step])      # contiguous: it is re-viewed as uint64 below
-    return (arr.__array_interface__["data"][0], arr.shape, arr.strides, str(arr.dtype),
-            int(sample.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(sample[: (sample.size // 8) * 8].view(np.uint64)))
-            if sample.size >= 8 else 0)
+def checksum(arr, nthreads=None):
+    """Full-content checksum of a C-contiguous array (every byte, position dependent) -> (int, int)."""
+    if not arr.flags.c_contiguous:
+        raise ValueError("checksum needs a C-contiguous array")
+    out = (ctypes.c_uint64 * 2)()
+    nt = nthreads or max(1, min(32, os.cpu_count() or 1))
+    _lib.check(_lib.lib().tomo_host_checksum(arr.ctypes.data, arr.nbytes, nt, out), "tomo_host_checksum")
+    return (int(out[0]), int(out[1]))
 
 
-def put(arr, vol):
+def _layout(arr):
+    return (arr.__array_interface__["data"][0], arr.shape, arr.strides, str(arr.dtype))
+
+
+def put(arr, vol, protect=True):
+    """Remember `vol` as the device copy of `arr`'s CURRENT content.  protect=True (arrays this package creates and
+    returns) write-protects the array; otherwise -- and always under TOMO_WRITEABLE_RESULTS -- its checksum is stored."""
+    if not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous:
+        return
     key = id(arr)
     try:
         ref = weakref.ref(arr, lambda _r, k=key: _cache.pop(k, None))
     except TypeError:
         return
-    _cache[key] = (ref, _fingerprint(arr), vol)
+    digest = None
+    if protect and not WRITEABLE_RESULTS:
+        arr.flags.writeable = False
+    else:
+        digest = checksum(arr)
+    _cache[key] = (ref, _layout(arr), digest, vol)
     _cache.move_to_end(key)
     while len(_cache) > _MAX:
         _cache.popitem(last=False)
@@ -42,12 +70,42 @@ def get(arr):
     ent = _cache.get(id(arr))
     if ent is None:
         return None
-    ref, fp, vol = ent
-    if ref() is not arr or fp != _fingerprint(arr):
+    ref, layout, digest, vol = ent
+    if ref() is not arr or layout != _layout(arr):
         _cache.pop(id(arr), None)
         return None
+    if arr.flags.writeable:
+        # the caller could have written into it: only a full comparison makes the cached copy usable
+        if digest is None:
+            STATS["miss_unverifiable"] += 1
+            _cache.pop(id(arr), None)
+            return None
+        if checksum(arr) != digest:
+            STATS["miss_edited"] += 1
+            _cache.pop(id(arr), None)
+            return None
+        STATS["hit_verified"] += 1
+    else:
+        if digest is not None and _base_writeable(arr):
+            # read-only view of memory somebody else can still write (not one of this package's own hand-outs)
+            if checksum(arr) != digest:
+                STATS["miss_edited"] += 1
+                _cache.pop(id(arr), None)
+                return None
+            STATS["hit_verified"] += 1
+        else:
+            STATS["hit_readonly"] += 1
     _cache.move_to_end(id(arr))
     return vol
+
+
+def _base_writeable(arr):
+    b = arr.base
+    while isinstance(b, np.ndarray):
+        if b.flags.writeable:
+            return True
+        b = b.base
+    return False
 
 
 def clear():

@@ -116,12 +116,14 @@ class ImageLoader:
             if n == 0:
                 return False
             stack = grey[:n] >= threshold                       # one contiguous bool (n, H, W) array
-            self.mask_images = [stack[i] for i in range(n)]
             if torch.cuda.is_available():
                 dev = torch.device("cuda", torch.cuda.current_device())
                 vol = pipeline.pack_threshold(grey_t[:n].to(dev, non_blocking=True), threshold)
                 torch.cuda.current_stream().synchronize()       # the pinned staging buffer is released on return
-                _devcache.put(stack, vol)                       # create_voxel_data finds it through the views' base
+                # create_voxel_data finds the volume through the views' base; the stack is write-protected BEFORE the
+                # views are made, so they are read-only too and the device copy cannot go stale
+                _devcache.put(stack, vol)
+            self.mask_images = [stack[i] for i in range(n)]
             return True
         except Exception as e:
             print(f"Loading failed: {e}")

@@ -2,7 +2,8 @@
 (/root/reference/voxel_processor.py:27-164), computed by the HIP kernels of libtomo_hip.so.
 
 Host arrays in, host arrays out (the reference's consumers need real np.ndarray); the bit-packed
-device copy of every returned volume is cached (see _devcache) so the orchestrator's next call does
+device copy of every returned volume is cached (see _devcache: returned volumes are write-protected, a
+writeable array is verified byte for byte before its cached copy is used) so the orchestrator's next call does
 not upload it again.  There is no CPU fallback: without a GPU / the built library these methods raise.
 """
 import numpy as np
@@ -116,6 +117,8 @@ class VoxelProcessor:
         self.side_2_count = side_2_count
         base = _common_base(mask_images)
         cached = _devcache.get(base) if base is not None else None
+        if cached is not None and not base.flags.writeable and any(m.flags.writeable for m in mask_images):
+            cached = None          # writeable views of a protected stack: its content may have changed behind the flag
         if close_ends:
             if cached is not None:                           # uploaded (and thresholded) by ImageLoader already
                 vol = pipeline.close_ends(cached)
