@@ -96,6 +96,14 @@ int tomo_pack_threshold(const uint8_t *grey, uint64_t *bits, int nz, int ny, int
  * on `nthreads` host threads.  Returns 0, TOMO_E_ARG, or -errno when the file cannot be written. */
 int tomo_obj_write(const char *path, const void *vertices, int vertex_is_double, int64_t nv, const int64_t *faces,
                    int64_t nf, int nthreads);
+/* The same file written by several processes (a Z-slab job; BASELINE configs[3] "seam-free OBJ export"): every rank
+ * formats ITS run of the vertex list (kind 0: float32 rows, 1: float64 rows) or of the face list (kind 2: int64 rows
+ * holding GLOBAL 0-based vertex indices) in host memory, learns the size, and -- once the sizes of all ranks are known
+ * -- writes the bytes at its offset of the shared file, which must exist.  Same formatter as tomo_obj_write: the file
+ * equals the one written from the gathered mesh.  A block lives until tomo_obj_block_free. */
+int tomo_obj_block_format(int kind, const void *h_rows, int64_t n, int nthreads, void **h_block, int64_t *h_nbytes);
+int tomo_obj_block_pwrite(const char *path, int64_t offset, const void *h_block);
+void tomo_obj_block_free(void *h_block);
 
 /* ---------------------------------------------------------------- scalar field ("SDF") */
 /* bits -> extended bits (reflect of the padded array + zero pad ring), see tomo_ext_*. */

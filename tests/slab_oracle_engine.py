@@ -109,3 +109,12 @@ class OracleEngine:
     def unique(self, vpos):
         u, inv = np.unique(vpos.numpy(), axis=0, return_inverse=True)
         return torch.from_numpy(u), torch.from_numpy(np.asarray(inv).reshape(-1).astype(np.int32))
+
+    def slice_counts(self, vol):
+        return torch.from_numpy(vol.arr().sum(axis=(1, 2)).astype(np.int64))
+
+    def bbox(self, vol):
+        idx = np.nonzero(vol.arr())
+        if len(idx[0]) == 0:
+            return None
+        return tuple(int(f(a)) for a in idx for f in (np.min, np.max))

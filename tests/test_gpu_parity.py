@@ -371,6 +371,59 @@ def test_inputs_not_mutated_and_cache_detects_edits(dev, monkeypatch):
     _devcache.clear()
 
 
+def test_device_failures_return_none_like_the_reference(dev, monkeypatch, capsys):
+    """surface_extractor.py:42,74-75: ANY exception inside extract_manifold_surface -> None (the orchestrator then falls
+    back to the point cloud).  Every guard of the device path is forced in turn; only a missing GPU / library raises."""
+    nz, ny, nx = 24, 40, 48
+    v = np.stack(O.ellipsoid_masks(nz, ny, nx))
+    depths = np.full(nz, 0.5)
+    se, vp = SurfaceExtractor(), VoxelProcessor()
+    good = se.extract_manifold_surface(v, depths, 1.0, 1.0)
+    assert good is not None
+    with monkeypatch.context() as m:                     # (1) active-voxel list beyond the 32-bit index range
+        m.setattr(pipeline, "LIST_LIMIT", 16)
+        pipeline._NA_HINT.clear()
+        assert se.extract_manifold_surface(v, depths, 1.0, 1.0) is None
+    with monkeypatch.context() as m:                     # (2) vertex / triangle totals beyond it
+        m.setattr(pipeline, "MESH_LIMIT", 16)
+        assert se.extract_manifold_surface(v, depths, 1.0, 1.0) is None
+    with monkeypatch.context() as m:                     # (3) the internal consistency check of the unique / remap stage
+
+        def boom(*a, **k):
+            raise _lib.TomoError("internal error: 3 triangle corners reference a missing vertex")
+        m.setattr(pipeline, "ensure_manifold_mesh", boom)
+        assert se.extract_manifold_surface(v, depths, 1.0, 1.0) is None
+    with monkeypatch.context() as m:                     # (4) a failing launch (status from the C ABI)
+        m.setattr(pipeline._lib, "check", lambda code, what: (_ for _ in ()).throw(_lib.TomoError(what + " failed")))
+        assert se.extract_manifold_surface(v.copy(), depths, 1.0, 1.0) is None
+    err = capsys.readouterr().err
+    assert err.count("surface extraction failed") == 4 and "32-bit indices" in err
+    # input the device path cannot take at all: the reference's own except clause would swallow its error as well
+    assert se.extract_manifold_surface(np.zeros((4, 4)), depths, 1.0, 1.0) is None
+    # smooth_voxel_data: a failure of the full sequence falls back to the closings alone (voxel_processor.py:93-95)
+    calls = []
+    real = pipeline.smooth
+
+    def flaky(vol, iterations, create_manifold):
+        calls.append(create_manifold)
+        if create_manifold:
+            raise _lib.TomoError("forced")
+        return real(vol, iterations, create_manifold)
+    with monkeypatch.context() as m:
+        m.setattr(pipeline, "smooth", flaky)
+        out = vp.smooth_voxel_data(v, 3, True)
+    assert calls == [True, False] and np.array_equal(out, O.smooth(v, 3, False))
+    # and the unavailable-GPU case still raises: there is no CPU path to fall back to
+    with monkeypatch.context() as m:
+        m.setattr(torch.cuda, "is_available", lambda: False)
+        with pytest.raises(_lib.TomoUnavailable):
+            se.extract_manifold_surface(v.copy(), depths, 1.0, 1.0)
+        with pytest.raises(_lib.TomoUnavailable):
+            vp.smooth_voxel_data(v.copy(), 3, True)
+    again = se.extract_manifold_surface(v, depths, 1.0, 1.0)
+    assert again[0].tobytes() == good[0].tobytes() and np.array_equal(again[1], good[1])
+
+
 def test_ellipsoid_cfg1_full_mesh(dev):
     c = np.load(os.path.join(G, "ellipsoid_64x128x128.npz"))
     nz, ny, nx = [int(s) for s in c["shape"]]

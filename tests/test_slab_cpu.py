@@ -39,12 +39,39 @@ def reference_mesh(v, depths, mm_y, mm_x):
     return se.extract_manifold_surface(sm, depths, mm_y, mm_x)
 
 
-def run_rank(comm, v, depths, mm_y, mm_x, out):
+def run_rank(comm, v, depths, mm_y, mm_x, out, obj_path=None):
     gz, ny, nx = v.shape
     job = slab.SlabJob(gz, ny, nx, comm, engine=OracleEngine())
     mask = torch.from_numpy(v[job.z0:job.z1].astype(np.uint8))
     verts, faces = job.run(mask, depths, mm_y, mm_x)
     out[comm.rank] = (verts.numpy().copy(), faces.numpy().copy(), job.vertex_offset, job.n_vertices_global)
+    # the consumers named in BASELINE configs[3] / [4]: one OBJ from all ranks, VolumeCalculator numbers of the whole stack
+    extras = {"vol_s": job.voxel_volume(mm_x, mm_y, depths), "vol_c": job.voxel_volume(mm_x, mm_y, depths, "created"),
+              "box_s": job.bounding_box(mm_x, mm_y, depths), "box_c": job.bounding_box(mm_x, mm_y, depths, "created"),
+              "counts": job.slice_counts()}
+    if obj_path is not None:
+        extras["obj_bytes"] = job.export_obj(obj_path, nthreads=2)
+    out[comm.rank] += (extras,)
+
+
+def check_consumers(out, v, depths, mm_y, mm_x, obj_path=None):
+    """Every rank's numbers equal the oracle's VolumeCalculator on the WHOLE volume; the OBJ equals the single-process file."""
+    vp, vc = O.VoxelProcessor(), O.VolumeCalculator()
+    created = vp.create_voxel_data(list(v), True, 0, v.shape[0], 0)
+    sm = vp.smooth_voxel_data(created, 3, True)
+    for r in range(len(out)):
+        ex = out[r][4]
+        assert np.array_equal(ex["counts"], sm.sum(axis=(1, 2)))
+        assert np.float64(ex["vol_s"]).tobytes() == np.float64(vc.calculate_voxel_volume_variable_depth(sm, mm_x, mm_y, depths)).tobytes()
+        assert np.float64(ex["vol_c"]).tobytes() == np.float64(vc.calculate_voxel_volume_variable_depth(created, mm_x, mm_y, depths)).tobytes()
+        for key, vol in (("box_s", sm), ("box_c", created)):
+            ref = vc.calculate_bounding_box_variable_depth(vol, mm_x, mm_y, depths)
+            assert all(np.asarray(ex[key][k], np.float64).tobytes() == np.asarray(ref[k], np.float64).tobytes() for k in ref)
+    if obj_path is not None:
+        verts = np.concatenate([o[0] for o in out])
+        faces = np.concatenate([o[1] for o in out])
+        data = open(obj_path, "rb").read()
+        assert data == O.obj_text(verts, faces).encode() and all(o[4]["obj_bytes"] == len(data) for o in out)
 
 
 def check(out, ref):
@@ -60,7 +87,7 @@ def check(out, ref):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_slab_threads_match_single_rank(world):
+def test_slab_threads_match_single_rank(world, tmp_path):
     shape = (72, 40, 70)
     v = make_volume(world, shape)
     depths = np.concatenate([np.full(8, 0.5), np.full(56, 0.25), np.full(8, 0.5)])
@@ -69,9 +96,11 @@ def test_slab_threads_match_single_rank(world):
     out = [None] * world
     errs = []
 
+    obj = str(tmp_path / "slab.obj")
+
     def target(c):
         try:
-            run_rank(c, v, depths, 0.7, 0.9, out)
+            run_rank(c, v, depths, 0.7, 0.9, out, obj)
         except BaseException as e:   # noqa: BLE001
             errs.append(e)
             raise
@@ -81,6 +110,7 @@ def test_slab_threads_match_single_rank(world):
     [t.join(300) for t in ts]
     assert not errs, errs
     check(out, ref)
+    check_consumers(out, v, depths, 0.7, 0.9, obj)
 
 
 def _gloo_worker(rank, world, port, shape, seed, tmpdir):
@@ -95,10 +125,13 @@ def _gloo_worker(rank, world, port, shape, seed, tmpdir):
         assert info["ranks"] == world and info["backend"] == "gloo"
         comm.reset_stats()
         out = {}
-        run_rank(comm, v, depths, 1.0, 1.0, out)
+        run_rank(comm, v, depths, 1.0, 1.0, out, os.path.join(tmpdir, "slab.obj"))
         assert comm.stats["calls"] > 0 and comm.stats["bytes_sent"] > 0
+        ex = out[rank][4]
         np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), v=out[rank][0], f=out[rank][1], off=out[rank][2],
-                 nvg=out[rank][3])
+                 nvg=out[rank][3], counts=ex["counts"], vol_s=ex["vol_s"], vol_c=ex["vol_c"], obj_bytes=ex["obj_bytes"],
+                 box_s=np.asarray([*ex["box_s"]["x"], *ex["box_s"]["y"], *ex["box_s"]["z"], *ex["box_s"]["dimensions"]], np.float64),
+                 box_c=np.asarray([*ex["box_c"]["x"], *ex["box_c"]["y"], *ex["box_c"]["z"], *ex["box_c"]["dimensions"]], np.float64))
     finally:
         td.destroy_process_group()
 
@@ -113,10 +146,15 @@ def test_slab_gloo_processes_match_single_rank(world, tmp_path):
     v = make_volume(seed, shape)
     ref = reference_mesh(v, np.full(shape[0], 0.5), 1.0, 1.0)
     out = []
+    def box(vec):
+        return {"x": tuple(vec[0:2]), "y": tuple(vec[2:4]), "z": tuple(vec[4:6]), "dimensions": tuple(vec[6:9])}
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
-        out.append((d["v"], d["f"], int(d["off"]), int(d["nvg"])))
+        out.append((d["v"], d["f"], int(d["off"]), int(d["nvg"]),
+                    {"counts": d["counts"], "vol_s": d["vol_s"], "vol_c": d["vol_c"], "obj_bytes": int(d["obj_bytes"]),
+                     "box_s": box(d["box_s"]), "box_c": box(d["box_c"])}))
     check(out, ref)
+    check_consumers(out, v, np.full(shape[0], 0.5), 1.0, 1.0, os.path.join(str(tmp_path), "slab.obj"))
 
 
 def test_slab_range_partition():

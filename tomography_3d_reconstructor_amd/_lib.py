@@ -40,6 +40,9 @@ SIGNATURES = {
     "tomo_bbox": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_threshold": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     "tomo_obj_write": (_c_i, [ctypes.c_char_p, _c_p, _c_i, _c_i64, _c_p, _c_i64, _c_i]),
+    "tomo_obj_block_format": (_c_i, [_c_i, _c_p, _c_i64, _c_i, ctypes.POINTER(_c_p), ctypes.POINTER(_c_i64)]),
+    "tomo_obj_block_pwrite": (_c_i, [ctypes.c_char_p, _c_i64, _c_p]),
+    "tomo_obj_block_free": (None, [_c_p]),
     "tomo_fill_holes_slice": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_close_ends_workspace_words": (_c_i64, [_c_i, _c_i, _c_i]),
     "tomo_close_ends_scan": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
@@ -85,6 +88,11 @@ class TomoError(RuntimeError):
     pass
 
 
+class TomoUnavailable(TomoError):
+    """No MI355X visible / libtomo_hip.so not built.  The one failure the drop-in classes never turn into the
+    reference's `return None`: there is no CPU fallback to hide behind."""
+
+
 def build(force=False):
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp", "Makefile"))]
@@ -101,7 +109,7 @@ def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(SO_PATH):
-            raise TomoError("libtomo_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            raise TomoUnavailable("libtomo_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C tomography_3d_reconstructor_amd/csrc` (there is no CPU fallback)")
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():

@@ -7,6 +7,7 @@ times these functions directly with the inputs already resident.
 
 Reference lines each function replaces are given in its docstring.
 """
+import math
 import os
 from dataclasses import dataclass
 
@@ -21,6 +22,8 @@ from . import _lib
 COUNTERS = {"unique_one_sort": 0, "unique_fallback": 0, "faces_direct": 0, "faces_fallback": 0}
 NA_HINTS = os.environ.get("TOMO_NA_HINTS", "1") not in ("", "0")   # marching_cubes: launch ahead of the first count download
 _NA_HINT = {}
+LIST_LIMIT = 2 ** 31        # active-voxel list entries / vertices / triangles one pass can index (int32 offsets in mc.hip, mesh.hip);
+MESH_LIMIT = 2 ** 31        # beyond them marching_cubes raises TomoError (the drop-in class then returns None, as the reference would)
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
 # extract_surface: do not materialise the parts of the float field that marching cubes cannot read (same mesh, ~0.4 ms less
 # per 1024^3 pass).  Off by default: the reference's path, and bench.py's roofline, speak of a dense per-voxel field.
@@ -111,15 +114,16 @@ def popcount_async(vol: BitVolume) -> torch.Tensor:
     return cnt
 
 
-def pack_threshold(grey: torch.Tensor, threshold: int) -> BitVolume:
-    """`img >= threshold` (image_loader.py:108) of a device uint8 (nz, ny, nx) grey stack, straight to a BitVolume."""
+def pack_threshold(grey: torch.Tensor, threshold) -> BitVolume:
+    """`img >= threshold` (image_loader.py:108) of a device uint8 (nz, ny, nx) grey stack, straight to a BitVolume.
+    For integer grey levels g >= t is g >= ceil(t), so a fractional threshold is rounded UP (199.5 -> 200)."""
     if grey.dim() != 3 or grey.dtype != torch.uint8:
         raise TypeError("grey stack must be uint8 (nz, ny, nx)")
     grey = grey.contiguous()
     nz, ny, nx = grey.shape
     L = _lib.lib()
     bits = torch.empty((nz, ny, L.tomo_words_per_row(nx)), dtype=torch.int64, device=grey.device)
-    _lib.check(L.tomo_pack_threshold(_p(grey), _p(bits), nz, ny, nx, int(threshold), _stream()), "tomo_pack_threshold")
+    _lib.check(L.tomo_pack_threshold(_p(grey), _p(bits), nz, ny, nx, int(math.ceil(threshold)), _stream()), "tomo_pack_threshold")
     return BitVolume(bits, (nz, ny, nx))
 
 
@@ -289,7 +293,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     na = None
     if hint:
         cap = int(hint * 1.25) + 4096
-        if cap < 2 ** 31:
+        if cap < LIST_LIMIT:
             vox_key = torch.empty(cap, dtype=torch.int64, device=dev)
             vox_counts = torch.empty(cap, dtype=torch.int32, device=dev)
             vox_flags = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -314,7 +318,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
         na = int(totals[0].item())
         if na == 0:
             return None
-        if na >= 2 ** 31:
+        if na >= LIST_LIMIT:
             raise _lib.TomoError("surface too large for 32-bit indices")
         vox_key = torch.empty(na, dtype=torch.int64, device=dev)
         _lib.check(L.tomo_mc_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(seg_act), _p(vox_key), st), "tomo_mc_list")
@@ -334,7 +338,7 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     _NA_HINT[hint_key] = na
     if nv == 0:
         return None
-    if nv >= 2 ** 31 or nf >= 2 ** 31:
+    if nv >= MESH_LIMIT or nf >= MESH_LIMIT:
         raise _lib.TomoError("mesh too large for 32-bit indices")
     # pass 4: vertices and triangles
     vkey = torch.empty(nv, dtype=torch.int64, device=dev)

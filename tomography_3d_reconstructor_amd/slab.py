@@ -308,6 +308,13 @@ class HipEngine:
     def remap_faces(self, faces32, gid32):
         return pipeline.remap_faces(faces32, gid32)
 
+    # reductions of the consumers (volume_calculator.py:23-35, 59-94) on the resident bit volume
+    def slice_counts(self, vol):
+        return pipeline.slice_counts(vol)
+
+    def bbox(self, vol):
+        return pipeline.bounding_box(vol)
+
 
 # ----------------------------------------------------------------------------- the job
 def slab_range(gz, rank, world):
@@ -330,6 +337,7 @@ class SlabJob:
         if self.z1 - self.z0 < self.halo + 1 and self.world > 1:
             raise ValueError("slab thinner than the halo (%d slices): use fewer ranks" % self.halo)
         self.active = None
+        self.created = self.smoothed = self.mesh = None     # this rank's share of the last run(), for the consumers below
 
     # -- step 1: closed slab (bits tensor of the owned slices)
     def _close_ends(self, vol, buf=None, room=0):
@@ -403,6 +411,8 @@ class SlabJob:
         sm = e.smooth(ext, self.iterations, self.create_manifold)
         # keep 2 halo slices for the field
         sb = e.bits(sm)
+        own = 0 if (first or self.world == 1) else H
+        self.created, self.smoothed = closed, e.from_bits(sb[own:own + nzl], (nzl, self.ny, self.nx))
         a = 0 if first else H - 2
         b = sb.shape[0] - (0 if last else H - 2)
         fvol = e.from_bits(sb[a:b], (b - a, self.ny, self.nx))
@@ -428,7 +438,8 @@ class SlabJob:
             vkey, ny = getattr(mesh, "vkey", None), getattr(mesh, "_ny", None)
             self._mesh_nz = getattr(mesh, "_nz", 0)
             e.finalize_vertices(vpos, slice_depths, mm_y, mm_x)
-        return self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
+        self.mesh = self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
+        return self.mesh
 
     # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
     def _global_numbering(self, vpos, faces32, slice_depths, dev, vkey=None, ny=None):
@@ -493,3 +504,104 @@ class SlabJob:
         f = gid[faces32.to(torch.int64)]
         keep = (f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])
         return f[keep]
+
+    # ------------------------------------------------------------------------- consumers of a finished run()
+    # BASELINE configs[3] asks for a "seam-free OBJ export" of the Z-slab job and configs[4] for a cross-check against
+    # volume_calculator.py: both work on what every rank already holds, exchange a few numbers, and give exactly what
+    # the single-GPU classes (OBJExporter, VolumeCalculator) give on the whole volume / the gathered mesh.
+    def _volume(self, which):
+        vol = {"smoothed": self.smoothed, "created": self.created}[which]
+        if vol is None:
+            raise RuntimeError("run() first")
+        return vol
+
+    def slice_counts(self, which="smoothed"):
+        """np.sum(volume[z]) for every slice of the WHOLE stack (volume_calculator.py:33) -> int64 (gz,) on every rank:
+        per-rank popcounts of the owned slices, one all-gather of ceil(gz / world) numbers."""
+        vol = self._volume(which)
+        c = self.eng.slice_counts(vol)
+        if not torch.is_tensor(c):
+            c = torch.as_tensor(np.asarray(c, dtype=np.int64))
+        room = -(-self.gz // self.world)
+        mine = torch.zeros(room, dtype=torch.int64, device=c.device)
+        mine[: c.shape[0]] = c
+        parts = self.comm.all_gather(mine)
+        out = []
+        for r in range(self.world):
+            a, b = slab_range(self.gz, r, self.world)
+            out.append(parts[r][: b - a].cpu().numpy())
+        return np.concatenate(out)
+
+    def index_box(self, which="smoothed"):
+        """(zmin, zmax, ymin, ymax, xmin, xmax) of the set voxels of the whole stack as np.int64, or None if it is empty
+        (np.where + min / max, volume_calculator.py:40-44, 62-72): per-rank boxes, one all-gather of six numbers."""
+        vol = self._volume(which)
+        b = self.eng.bbox(vol)
+        big = np.iinfo(np.int64).max
+        mine = [big, -1, big, -1, big, -1] if b is None else [b[0] + self.z0, b[1] + self.z0, b[2], b[3], b[4], b[5]]
+        dev = self.eng.bits(vol).device
+        parts = np.stack([p.cpu().numpy() for p in self.comm.all_gather(torch.tensor(mine, dtype=torch.int64, device=dev))])
+        if parts[:, 1].max() < 0:
+            return None
+        return tuple(np.int64(parts[:, k].min() if k % 2 == 0 else parts[:, k].max()) for k in range(6))
+
+    def voxel_volume(self, mm_per_pixel_x, mm_per_pixel_y, slice_depths, which="smoothed"):
+        """== VolumeCalculator.calculate_voxel_volume_variable_depth(whole volume, ...) (volume_calculator.py:23-35)."""
+        from .volume_calculator import volume_from_slice_counts
+        if len(slice_depths) == 0:
+            return 0.0
+        return volume_from_slice_counts(self.slice_counts(which), mm_per_pixel_x, mm_per_pixel_y, slice_depths)
+
+    def bounding_box(self, mm_per_pixel_x, mm_per_pixel_y, slice_depths, which="smoothed"):
+        """== VolumeCalculator.calculate_bounding_box_variable_depth(whole volume, ...) (volume_calculator.py:59-94)."""
+        from .volume_calculator import box_variable_depth
+        return box_variable_depth(self.index_box(which), mm_per_pixel_x, mm_per_pixel_y, slice_depths)
+
+    def export_obj(self, path, nthreads=None):
+        """ONE OBJ file of the whole mesh, byte for byte what OBJExporter.export_to_obj writes from the gathered
+        (vertices, faces) (obj_exporter.py:17-37) -- without gathering it: every rank formats its run of the vertex list
+        and of the face list (global indices) on its host cores, the byte counts are all-gathered, rank 0 lays the file
+        out (header, total size) and every rank writes its two blocks at their offsets.  `path` must name the same file
+        on every rank (the ranks of one node share the file system).  Returns the file size."""
+        import os
+        from . import _lib
+        if self.mesh is None:
+            raise RuntimeError("run() first")
+        L = _lib.lib()
+        verts, faces = self.mesh
+        dev = verts.device
+        v = np.ascontiguousarray(verts.detach().cpu().numpy(), dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces.detach().cpu().numpy(), dtype=np.int64).reshape(-1, 3)
+        nt = int(nthreads or max(1, min(16, (os.cpu_count() or 1) // max(self.world, 1))))
+        blocks = []
+        try:
+            import ctypes
+            sizes = []
+            for kind, rows in ((0, v), (2, f)):
+                h, nb = ctypes.c_void_p(), ctypes.c_int64()
+                _lib.check(L.tomo_obj_block_format(kind, rows.ctypes.data if len(rows) else None, len(rows), nt,
+                                                   ctypes.byref(h), ctypes.byref(nb)), "tomo_obj_block_format")
+                blocks.append(h)
+                sizes.append(int(nb.value))
+            table = torch.stack(self.comm.all_gather(torch.tensor(sizes + [len(v), len(f)], dtype=torch.int64, device=dev))).cpu().numpy()
+            header = b"# Tomography reconstruction model\n# %d vertices, %d faces\n\n" % (int(table[:, 2].sum()), int(table[:, 3].sum()))
+            v_at = len(header) + int(table[: self.rank, 0].sum())
+            sep_at = len(header) + int(table[:, 0].sum())
+            f_at = sep_at + 1 + int(table[: self.rank, 1].sum())
+            total = sep_at + 1 + int(table[:, 1].sum())
+            if self.rank == 0:
+                with open(path, "wb") as fh:
+                    fh.write(header)
+                    fh.truncate(total)
+                    fh.seek(sep_at)
+                    fh.write(b"\n")
+            self.comm.all_gather(torch.zeros(1, dtype=torch.int64, device=dev))          # the file exists before anyone writes into it
+            for h, at in zip(blocks, (v_at, f_at)):
+                rc = L.tomo_obj_block_pwrite(os.fsencode(path), at, h)
+                if rc:
+                    raise OSError(-rc, os.strerror(-rc), path) if rc < -1 else _lib.TomoError("tomo_obj_block_pwrite")
+            self.comm.all_gather(torch.zeros(1, dtype=torch.int64, device=dev))          # complete on return, on every rank
+            return total
+        finally:
+            for h in blocks:
+                L.tomo_obj_block_free(h)

@@ -73,59 +73,54 @@ class EllipsoidSliceGenerator:
         out = Image.fromarray(self.middle_slice, mode="L").transform((w, h), Image.AFFINE, coeffs, resample=Image.BILINEAR)
         return np.asarray(out, dtype=np.uint8)
 
-    def generate_slices(self, num_slices: int, output_dir: str = "slices") -> List[str]:
-        """:79-105: n slices over z in [-c, c], saved as Mask_001.png ... in order of increasing area."""
+    def _depth_scale(self):
+        """The ellipsoid's third semi-axis: the smaller of the two fitted ones (:83, :110)."""
+        return min(self.ellipse_params['semi_major_axis'], self.ellipse_params['semi_minor_axis'])
+
+    @staticmethod
+    def _save(img, path):
         from PIL import Image
+        Image.fromarray(img, mode="L").save(path)
+        return path
+
+    def generate_slices(self, num_slices: int, output_dir: str = "slices") -> List[str]:
+        """(:79-105) `num_slices` heights evenly spaced over [-c, c]; the files are numbered Mask_001.png ... by
+        ascending mask area (ties keep their height order), so the list runs from the empty slices to the mask itself."""
         os.makedirs(output_dir, exist_ok=True)
-        c = min(self.ellipse_params['semi_major_axis'], self.ellipse_params['semi_minor_axis'])
-        data = []
-        for i, z in enumerate(np.linspace(-c, c, num_slices)):
-            img = self._generate_slice_at_height(z, c)
-            data.append((i, z, img, np.sum(img > 0)))
-        data.sort(key=lambda x: x[3])
-        saved = []
-        for number, (_, _, img, _) in enumerate(data, 1):
-            path = os.path.join(output_dir, f"Mask_{number:03d}.png")
-            Image.fromarray(img, mode="L").save(path)
-            saved.append(path)
-        return saved
+        c = self._depth_scale()
+        images = [self._generate_slice_at_height(z, c) for z in np.linspace(-c, c, num_slices)]
+        by_area = np.argsort([int(np.count_nonzero(img)) for img in images], kind="stable")
+        return [self._save(images[k], os.path.join(output_dir, "Mask_%03d.png" % (pos + 1))) for pos, k in enumerate(by_area)]
 
     def generate_slices_half_ellipsoid(self, num_slices: int, output_dir: str = "slices",
                                        num_start: int = 28, increase: bool = True) -> List[str]:
-        """:107-143: num_slices + 2 slices over z in [0, c] named Mask_Patient_<n>.png, then the two extreme files
-        (the mask itself and the vanishing slice) are deleted again; the returned list still names all of them."""
-        from PIL import Image
-        c = min(self.ellipse_params['semi_major_axis'], self.ellipse_params['semi_minor_axis'])
-        z_positions = np.linspace(0, c, num_slices + 2)
-        if increase:
-            num_end = num_start + 1 + num_slices
-        else:
-            num_end = num_start - num_slices - 1
-            num_start, num_end = num_end, num_start
-        saved = []
-        number_range = list(range(num_start, num_end + 1))
-        for i, number in enumerate(number_range):
-            z_index = i if increase else len(number_range) - 1 - i
-            z = z_positions[z_index] if z_index < len(z_positions) else c
-            path = os.path.join(output_dir, f"Mask_Patient_{number}.png")
-            Image.fromarray(self._generate_slice_at_height(z, c), mode="L").save(path)
-            saved.append(path)
-        os.remove(saved[0])
-        os.remove(saved[-1])
-        return saved
+        """(:107-143) One flank of the stack: num_slices + 2 heights evenly spaced from 0 (the mask itself) to c (the
+        vanishing slice).  File Mask_Patient_<num_start> is height 0; the numbers run away from it upwards
+        (increase=True) or downwards, one per height.  Files are written in ascending number order, then the two ends of
+        the run -- the copy of the mask and the empty slice -- are deleted again.  The returned list names every file
+        that was written, the two deleted ones included."""
+        c = self._depth_scale()
+        heights = np.linspace(0, c, num_slices + 2)
+        step = 1 if increase else -1
+        numbered = sorted((num_start + step * k, z) for k, z in enumerate(heights))
+        written = [self._save(self._generate_slice_at_height(z, c), os.path.join(output_dir, f"Mask_Patient_{number}.png"))
+                   for number, z in numbered]
+        for path in (written[0], written[-1]):
+            os.remove(path)
+        return written
 
 
 def generate_slices_from_mask(mask_path, n_slices, output_directory, num_start, increase):
-    """simple_generator.py:6-20."""
-    if os.path.exists(output_directory):
-        shutil.rmtree(output_directory)
+    """simple_generator.py:6-20: start from an EMPTY `output_directory` (an existing one is removed), then write the
+    half-ellipsoid flank of `mask_path` into it.  Problems are reported on the console, never raised."""
+    shutil.rmtree(output_directory, ignore_errors=False) if os.path.exists(output_directory) else None
     os.makedirs(output_directory, exist_ok=True)
     if not os.path.exists(mask_path):
         print(f"Error: Image '{mask_path}' not found.")
         return
     try:
-        generator = EllipsoidSliceGenerator(mask_path)
-        slice_files = generator.generate_slices_half_ellipsoid(n_slices, output_directory, num_start, increase)
-        print(f"Generated {len(slice_files)} slices in '{output_directory}'")
-    except Exception as e:
+        files = EllipsoidSliceGenerator(mask_path).generate_slices_half_ellipsoid(n_slices, output_directory, num_start, increase)
+    except Exception as e:                       # noqa: BLE001 -- reported, as the reference does
         print(f"Error: {e}")
+        return
+    print(f"Generated {len(files)} slices in '{output_directory}'")

@@ -2,6 +2,7 @@
 same class and methods; the field ("SDF") fill, Lewiner marching cubes, vertex finalisation and the
 unique/remap stage run as HIP kernels on the MI355X.  No CPU fallback.
 """
+import sys
 from typing import Optional, Tuple
 
 import numpy as np
@@ -23,18 +24,27 @@ class SurfaceExtractor:
                                  add_padding: bool = True) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         """surface_extractor.py:34-75.  `smooth` is unused there as well.  Returns (vertices float32
         (V,3) in (z_mm,y_mm,x_mm), faces int64 (F,3)) or None where the reference returns None
-        (empty volume, level outside the field range, volume thinner than 2 voxels)."""
-        vol = to_device_volume(volume_data)
-        res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
-        if res is None:
+        (empty volume, level outside the field range, volume thinner than 2 voxels) -- and, as there (:74-75: any
+        exception -> None, the orchestrator then falls back to the point cloud), when the device path fails: a surface
+        too large for its 32-bit indices, a failed launch, out of memory.  One line on stderr says which.  Only a
+        missing GPU / library raises: that is not a property of the input."""
+        try:
+            vol = to_device_volume(volume_data)
+            res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
+            if res is None:
+                return None
+            verts, faces = res
+            vertices = to_host_array(verts.contiguous())
+            faces_np = to_host_array(faces.contiguous())
+            if len(faces_np) == 0:
+                faces_np = np.array([])
+            print(f"Surface: {len(vertices)} vertices, {len(faces_np)} faces")
+            return vertices, faces_np
+        except pipeline._lib.TomoUnavailable:
+            raise
+        except Exception as e:                                           # noqa: BLE001 -- the reference catches Exception here
+            print(f"tomography_3d_reconstructor_amd: surface extraction failed ({e}); returning None", file=sys.stderr)
             return None
-        verts, faces = res
-        vertices = to_host_array(verts.contiguous())
-        faces_np = to_host_array(faces.contiguous())
-        if len(faces_np) == 0:
-            faces_np = np.array([])
-        print(f"Surface: {len(vertices)} vertices, {len(faces_np)} faces")
-        return vertices, faces_np
 
     def calculate_mesh_volume(self, vertices: np.ndarray, faces: np.ndarray) -> float:
         """surface_extractor.py:128-139 (device tree reduction: equal to the sequential sum to ~1e-12 rel)."""
@@ -50,5 +60,14 @@ class SurfaceExtractor:
     def _upload(vertices, faces):
         dev = _device()
         v = torch.from_numpy(np.ascontiguousarray(vertices, dtype=np.float32)).to(dev)
-        f = torch.from_numpy(np.ascontiguousarray(faces, dtype=np.int64).reshape(-1, 3)).to(dev)
+        fh = np.ascontiguousarray(faces, dtype=np.int64).reshape(-1, 3)
+        if fh.size:
+            # NumPy indexing (surface_extractor.py:133-136, :144-146) wraps negative indices and raises IndexError beyond
+            # the vertex list; the kernel reads verts[3 * index] unchecked, so both are settled here
+            lo, hi = int(fh.min()), int(fh.max())
+            if hi >= len(v) or lo < -len(v):
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (hi if hi >= len(v) else lo, len(v)))
+            if lo < 0:
+                fh = np.where(fh < 0, fh + len(v), fh)
+        f = torch.from_numpy(fh).to(dev)
         return v, f

@@ -6,6 +6,8 @@ device copy of every returned volume is cached (see _devcache: returned volumes 
 writeable array is verified byte for byte before its cached copy is used) so the orchestrator's next call does
 not upload it again.  There is no CPU fallback: without a GPU / the built library these methods raise.
 """
+import sys
+
 import numpy as np
 import torch
 
@@ -14,7 +16,7 @@ from . import _devcache, pipeline
 
 def _device():
     if not torch.cuda.is_available():
-        raise pipeline._lib.TomoError("no MI355X visible: the HIP path has no CPU fallback")
+        raise pipeline._lib.TomoUnavailable("no MI355X visible: the HIP path has no CPU fallback")
     return torch.device("cuda", torch.cuda.current_device())
 
 
@@ -138,9 +140,17 @@ class VoxelProcessor:
         return self.voxel_data
 
     def smooth_voxel_data(self, voxel_data: np.ndarray, iterations: int = 3, create_manifold: bool = True) -> np.ndarray:
-        """voxel_processor.py:79-97 (binary_opening + `iterations` x binary_closing, 3-D cross)."""
+        """voxel_processor.py:79-97 (binary_opening + `iterations` x binary_closing, 3-D cross).  Like the reference
+        (:93-95) a failure of the full sequence falls back to the closings alone; only a missing GPU / library raises
+        on the first attempt (there is no CPU path to fall back to)."""
         vol = to_device_volume(voxel_data)
-        return to_host_volume(pipeline.smooth(vol, iterations, create_manifold))
+        try:
+            return to_host_volume(pipeline.smooth(vol, iterations, create_manifold))
+        except pipeline._lib.TomoUnavailable:
+            raise
+        except Exception as e:                                           # noqa: BLE001 -- the reference catches Exception here
+            print(f"tomography_3d_reconstructor_amd: smoothing failed ({e}); closings only", file=sys.stderr)
+            return to_host_volume(pipeline.smooth(vol, iterations, False))
 
     def generate_point_cloud(self, voxel_data: np.ndarray, mm_per_pixel_x: float, mm_per_pixel_y: float,
                              slice_depths: np.ndarray, subsample_factor: int = 1) -> np.ndarray:
