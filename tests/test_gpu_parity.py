@@ -494,11 +494,17 @@ def test_mesh_properties_and_determinism_256(dev):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_slab_ranks_on_one_gpu_match_single_gpu(dev, world):
+def test_slab_ranks_on_one_gpu_match_single_gpu(dev, world, tmp_path):
     """The multi-GPU (Z-slab) path with the HIP engine: `world` rank threads share this GPU and talk through the
-    in-process communicator; the concatenated result must be byte-identical to the single-GPU mesh."""
+    in-process communicator; the concatenated result must be byte-identical to the single-GPU mesh, the OBJ file the
+    ranks write together to the single-GPU export, and the whole-stack volume / bounding box every rank reports to
+    VolumeCalculator's numbers (variable slice depths, anisotropic pixels)."""
+    import contextlib
+    import io
     import threading
     from tomography_3d_reconstructor_amd import slab
+    from tomography_3d_reconstructor_amd.obj_exporter import OBJExporter
+    from tomography_3d_reconstructor_amd.volume_calculator import VolumeCalculator
     nz, ny, nx = 96, 80, 112
     rng = np.random.default_rng(3)
     v = np.stack(O.ellipsoid_masks(nz, ny, nx))
@@ -517,8 +523,10 @@ def test_slab_ranks_on_one_gpu_match_single_gpu(dev, world):
             with torch.cuda.stream(torch.cuda.Stream()):
                 mask = torch.from_numpy(v[job.z0:job.z1].astype(np.uint8)).to(dev)
                 verts, faces = job.run(mask, depths, 0.7, 0.9)
+                extras = (job.voxel_volume(0.9, 0.7, depths), job.bounding_box(0.9, 0.7, depths),
+                          job.voxel_volume(0.9, 0.7, depths, "created"), job.export_obj(str(tmp_path / "slab.obj"), nthreads=2))
                 torch.cuda.current_stream().synchronize()
-            out[c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.vertex_offset, job.n_vertices_global)
+            out[c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.vertex_offset, job.n_vertices_global, extras)
         except BaseException as e:   # noqa: BLE001
             errs.append(e)
             raise
@@ -532,6 +540,19 @@ def test_slab_ranks_on_one_gpu_match_single_gpu(dev, world):
     assert out[0][3] == rv.shape[0]
     assert verts.tobytes() == rv.cpu().numpy().tobytes()
     assert np.array_equal(faces, rf.cpu().numpy())
+    # consumers: VolumeCalculator on the whole (host) volumes, OBJExporter on the single-GPU mesh
+    vc = VolumeCalculator()
+    created_h, smoothed_h = to_np(pipeline.close_ends(to_vol(v, dev))), to_np(vol)
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert OBJExporter().export_to_obj(rv.cpu().numpy(), rf.cpu().numpy(), str(tmp_path / "single.obj"))
+    single = open(tmp_path / "single.obj", "rb").read()
+    assert open(tmp_path / "slab.obj", "rb").read() == single
+    ref_box = vc.calculate_bounding_box_variable_depth(smoothed_h, 0.9, 0.7, depths)
+    for o in out:
+        vol_s, box_s, vol_c, obj_bytes = o[4]
+        assert vol_s == vc.calculate_voxel_volume_variable_depth(smoothed_h, 0.9, 0.7, depths)
+        assert vol_c == vc.calculate_voxel_volume_variable_depth(created_h, 0.9, 0.7, depths)
+        assert box_s == ref_box and obj_bytes == len(single)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
