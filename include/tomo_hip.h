@@ -69,6 +69,8 @@ int tomo_popcount(const uint64_t *bits, int nz, int ny, int nx, unsigned long lo
 /* ndimage.binary_fill_holes on slice `z` when that slice is non-empty (voxel_processor.py:60-62,66-68).
  * scratch: ny * wx + 8 words.  Iterates on the device until the flood is stable. */
 int tomo_fill_holes_slice(uint64_t *bits, int nz, int ny, int nx, int z, uint64_t *scratch, void *stream);
+/* The same for slices 0 and nz - 1 in one launch (the two floods are independent); same scratch. */
+int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream);
 /* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
  * workspace: tomo_close_ends_workspace_words() uint64 words. */
 int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);

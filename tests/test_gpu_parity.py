@@ -154,6 +154,63 @@ def test_fill_holes_spiral(dev):
     assert np.array_equal(got[0], img) and np.array_equal(got[2], img)
 
 
+def _fill_cases(ny, nx, rng):
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    r2 = ((xx - (nx - 1) / 2) / (0.42 * nx)) ** 2 + ((yy - (ny - 1) / 2) / (0.40 * ny)) ** 2
+    spiral = np.zeros((ny, nx), bool)
+    spiral[2:-2, 2:-2] = True
+    for k in range(4, min(ny, nx) // 2, 4):                # a corridor of background winding into a solid block
+        spiral[k, k:nx - k] = False
+        spiral[k:ny - k, nx - k - 1] = False
+        spiral[ny - k - 1, k + 2:nx - k] = False
+        spiral[k + 4:ny - k, k + 2] = False
+    spiral[4, 0:6] = False
+    comb = np.zeros((ny, nx), bool)                        # vertical teeth: floods travel straight through many bands
+    comb[3:-3, 3:-3:5] = True
+    comb[ny // 2, 3:-3] = True
+    return {"ellipse": r2 <= 1.0, "ring": (r2 <= 1.0) & (r2 >= 0.4), "noise50": rng.random((ny, nx)) < 0.5,
+            "noise62": rng.random((ny, nx)) < 0.38, "spiral": spiral, "comb": comb, "empty": np.zeros((ny, nx), bool),
+            "full": np.ones((ny, nx), bool), "frame": ~np.pad(np.zeros((ny - 2, nx - 2), bool), 1, constant_values=True) ^ True}
+
+
+@pytest.mark.parametrize("shape", [(200, 300), (257, 130), (96, 1000), (513, 64), (1024, 1024)])
+def test_fill_holes_many_workgroups_vs_oracle(dev, shape, monkeypatch):
+    """tomo_fill_holes_ends / _slice on slices large enough for the band kernel (row bands in LDS, grid barrier, carry
+    fold across bands): == ndimage.binary_fill_holes as restated by the oracle, for both end slices at once with
+    DIFFERENT content, and == the one-workgroup kernel (TOMO_FILL_ONE_BLOCK)."""
+    ny, nx = shape
+    rng = np.random.default_rng(ny + nx)
+    cases = _fill_cases(ny, nx, rng)
+    names = list(cases)
+    L = _lib.lib()
+    for i, name in enumerate(names):
+        a, b = cases[name], cases[names[(i + 3) % len(names)]]
+        mid = rng.random((ny, nx)) < 0.5
+        v = np.stack([a, mid, b])
+        exp = v.copy()
+        for z in (0, 2):
+            if exp[z].any():
+                exp[z] = O.fill_holes_2d(exp[z])
+        vol = to_vol(v, dev)
+        scratch = torch.full((ny * vol.bits.shape[2] + 8,), -1, dtype=torch.int64, device=dev)   # garbage: the launch must not rely on zeros
+        _lib.check(L.tomo_fill_holes_ends(vol.bits.data_ptr(), 3, ny, nx, scratch.data_ptr(), None), "fill")
+        got = to_np(vol)
+        assert np.array_equal(got, exp), (name, "ends")
+        ctrl = scratch[:16].cpu().numpy()
+        assert ctrl[2] in (0, -1) and ctrl[10] in (0, -1), "a grid barrier of the band kernel was abandoned"
+        vol1 = to_vol(v, dev)
+        _lib.check(L.tomo_fill_holes_slice(vol1.bits.data_ptr(), 3, ny, nx, 0, scratch.data_ptr(), None), "fill")
+        assert np.array_equal(to_np(vol1)[0], exp[0]) and np.array_equal(to_np(vol1)[2], v[2]), (name, "slice")
+    with monkeypatch.context() as m:
+        m.setenv("TOMO_FILL_ONE_BLOCK", "1")
+        v = np.stack([cases["spiral"], cases["ring"], cases["noise62"]])
+        vol = to_vol(v, dev)
+        scratch = torch.empty(ny * vol.bits.shape[2] + 8, dtype=torch.int64, device=dev)
+        _lib.check(L.tomo_fill_holes_ends(vol.bits.data_ptr(), 3, ny, nx, scratch.data_ptr(), None), "fill")
+        got = to_np(vol)
+        assert np.array_equal(got[0], O.fill_holes_2d(v[0])) and np.array_equal(got[2], O.fill_holes_2d(v[2]))
+
+
 # ------------------------------------------------------------------ field
 @pytest.mark.parametrize("shape", [(5, 6, 7), (4, 9, 64), (6, 5, 150), (3, 12, 255), (7, 8, 256), (5, 40, 260),
                                    (2, 3, 1), (1, 1, 5), (9, 7, 1030)])

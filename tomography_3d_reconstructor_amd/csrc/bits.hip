@@ -276,15 +276,281 @@ __global__ __launch_bounds__(FH_THREADS) void fill_holes_kernel(u64 *slice, u64 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same flood on MANY workgroups (the kernel above uses one CU of 256 and took 184 us for a filled 1024^2 ellipse,
+// 823 us at 2048^2 -- profiles/r02_fill_holes.md).  The slice is cut into bands of rows; a band (free mask F and reach
+// set R) lives in its workgroup's LDS.  Inside a band the flood runs to convergence with COMPLETE sweeps: along rows
+// (in-word flood + a carry chain across the words, both directions) and along bit columns (a carry chain down and up the
+// rows) -- a sweep moves the flood arbitrarily far along its axis, so convex shapes take one round.  Between bands only
+// three words per word column travel: what reaches the band's bottom row (Gd) and top row (Gu), and which bit columns
+// are free all the way through (P).  After a grid barrier every band folds the bands above / below it into a carry-in
+// for its top / bottom row (c = G | (P & c), the close-ends carry chain again) and, if that adds anything, converges
+// again.  Rounds repeat until no band received a new bit; two grid barriers for a slice whose flood needs no detour.
+// Both end slices of a volume run in one launch (blockIdx.y).
+// The grid barrier needs all workgroups of a slice resident at once: at most 256 per slice, of 256 threads (the launcher falls
+// back to the one-workgroup kernel otherwise) on a 256-CU part; its spin is bounded, so every wave terminates.
+#define FB_THREADS 256
+#define FB_MAX_BANDS 256
+#define FB_LDS_WORDS 4096            // RB * wx <= this: F and R of a band in 64 KiB
+#define FB_FOLD 8                    // partial folds per word column and direction (carry fold across the bands)
+
+struct FillBands {
+    u64 *slice[2];
+    u64 *ctrl;        // [2][8]: bar, any, err, -, flag[4]
+    u64 *comp;        // [2][3][nb][wx]: Gd, Gu, P
+    int ny, nx, wx, RB, nb;
+};
+
+__device__ static inline bool fb_barrier(u64 *bar, u64 target)
+{   // all workgroups of this slice; false if the wait was abandoned (never expected: every workgroup is resident)
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd((unsigned long long *)bar, 1ull);
+        int spins = 0;
+        ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) { ok = 0; break; }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+// R <- complete row floods (returns through *chg whether any word changed); all threads of the workgroup
+__device__ static inline void fb_sweep_rows(u64 *__restrict__ R, const u64 *__restrict__ F, int rows, int wx, int *chg)
+{
+    const int tid = threadIdx.x;
+    int c = 0;
+    for (int i = tid; i < rows * wx; i += FB_THREADS) {
+        const u64 r = R[i], nr = word_flood(r, F[i]);
+        if (nr != r) { R[i] = nr; c = 1; }
+    }
+    __syncthreads();
+    for (int r = tid; r < rows; r += FB_THREADS) {       // carries across the words of a row: one thread per row
+        u64 *Rr = R + r * wx;
+        const u64 *Fr = F + r * wx;
+        u64 carry = 0;
+        for (int w = 0; w < wx; w++) {                    // towards higher x
+            u64 v = Rr[w];
+            if (carry & Fr[w] & ~v) { v = word_flood(v | 1ull, Fr[w]); Rr[w] = v; c = 1; }
+            carry = v >> 63;
+        }
+        carry = 0;
+        for (int w = wx - 1; w >= 0; w--) {               // towards lower x
+            u64 v = Rr[w];
+            if ((carry << 63) & Fr[w] & ~v) { v = word_flood(v | (1ull << 63), Fr[w]); Rr[w] = v; c = 1; }
+            carry = v & 1ull;
+        }
+    }
+    if (c) *chg = 1;
+    __syncthreads();
+}
+
+// R <- complete floods along the bit columns (down, then up); one thread per word column
+__device__ static inline void fb_sweep_columns(u64 *__restrict__ R, const u64 *__restrict__ F, int rows, int wx, int *chg)
+{
+    int c = 0;
+    for (int w = threadIdx.x; w < wx; w += FB_THREADS) {
+        u64 carry = R[w];
+        for (int r = 1; r < rows; r++) {
+            const u64 v = R[r * wx + w], nv = v | (carry & F[r * wx + w]);
+            if (nv != v) { R[r * wx + w] = nv; c = 1; }
+            carry = nv;
+        }
+        for (int r = rows - 2; r >= 0; r--) {
+            const u64 v = R[r * wx + w], nv = v | (carry & F[r * wx + w]);
+            if (nv != v) { R[r * wx + w] = nv; c = 1; }
+            carry = nv;
+        }
+    }
+    if (c) *chg = 1;
+    __syncthreads();
+}
+
+__device__ static inline void fb_converge(u64 *R, const u64 *F, int rows, int wx, int *s_chg)
+{
+    for (int it = 0;; it++) {
+        if (threadIdx.x == 0) *s_chg = 0;
+        __syncthreads();
+        fb_sweep_rows(R, F, rows, wx, s_chg);
+        const int ch = *s_chg;
+        __syncthreads();
+        if (it > 0 && !ch) break;             // the column sweep before was complete and this row sweep added nothing
+        if (threadIdx.x == 0) *s_chg = 0;
+        __syncthreads();
+        fb_sweep_columns(R, F, rows, wx, s_chg);
+        const int cv = *s_chg;
+        __syncthreads();
+        if (!cv) break;                       // the row sweep before was complete and this column sweep added nothing
+    }
+}
+
+__global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const FillBands p)
+{
+    extern __shared__ u64 fb_lds[];
+    __shared__ int s_chg, s_any;
+    const int tid = threadIdx.x, b = blockIdx.x, sl = blockIdx.y;
+    const int wx = p.wx, nb = p.nb;
+    u64 *F = fb_lds, *R = fb_lds + p.RB * wx;
+    u64 *fold_g = R + p.RB * wx, *fold_p = fold_g + 2 * FB_FOLD * wx;
+    u64 *slice = p.slice[sl];
+    u64 *ctrl = p.ctrl + 8 * sl;
+    u64 *Gd = p.comp + (size_t)sl * 3 * nb * wx, *Gu = Gd + (size_t)nb * wx, *P = Gu + (size_t)nb * wx;
+    const int y0 = b * p.RB, rows = (p.ny - y0 < p.RB) ? p.ny - y0 : p.RB;
+    const u64 tailmask = (p.nx & 63) ? ((1ull << (p.nx & 63)) - 1ull) : ~0ull;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    int any = 0;
+    for (int i = tid; i < rows * wx; i += FB_THREADS) {
+        const int r = i / wx, w = i - r * wx, y = y0 + r;
+        const u64 v = slice[(int64_t)y * wx + w];
+        const u64 valid = (w == wx - 1) ? tailmask : ~0ull;
+        const u64 freem = ~v & valid;
+        u64 seed = 0;                                           // background pixels on the image border
+        if (y == 0 || y == p.ny - 1) seed = freem;
+        if (w == 0) seed |= freem & 1ull;
+        if (w == (p.nx - 1) / 64) seed |= freem & (1ull << ((p.nx - 1) & 63));
+        F[i] = freem;
+        R[i] = seed;
+        any |= v != 0;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (tid == 0 && s_any) atomicOr((unsigned long long *)&ctrl[1], 1ull);
+    fb_converge(R, F, rows, wx, &s_chg);
+    for (int w = tid; w < wx; w += FB_THREADS) {
+        u64 pr = ~0ull;
+        for (int r = 0; r < rows; r++) pr &= F[r * wx + w];
+        P[(size_t)b * wx + w] = pr;
+        Gd[(size_t)b * wx + w] = R[(rows - 1) * wx + w];
+        Gu[(size_t)b * wx + w] = R[w];
+    }
+    u64 k = 0;
+    if (!fb_barrier(&ctrl[0], (u64)nb * ++k)) { if (tid == 0) ctrl[2] = 1; return; }
+    // np.any(slice) guard of the reference (voxel_processor.py:60,66): an empty slice stays as it is
+    if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const int64_t max_rounds = (int64_t)p.ny * wx * 64 + 2;
+    for (int64_t g = 0; g < max_rounds; g++) {
+        if (tid == 0) s_chg = 0;
+        __syncthreads();
+        int got = 0;
+        // carry-in from the bands above (Gd, downwards) and below (Gu, upwards): c = G | (P & c) over up to nb bands.
+        // Two levels, so that no thread waits on a long chain of dependent memory round trips: FB_FOLD threads per word
+        // column each fold a run of bands into one (g, p) pair (their loads are independent and issued eight at a time),
+        // then one thread per column folds the FB_FOLD pairs from LDS.
+        const int run = (nb + FB_FOLD - 1) / FB_FOLD;
+        for (int it = tid; it < wx * FB_FOLD * 2; it += FB_THREADS) {
+            const int w = it % wx, j = (it / wx) % FB_FOLD, up = it / (wx * FB_FOLD);
+            // down: bands [j run, (j+1) run) below b, ascending; up: the same run of bands above b, taken descending
+            int a0 = j * run, a1 = a0 + run < nb ? a0 + run : nb;
+            if (!up) { if (a1 > b) a1 = b; } else { if (a0 < b + 1) a0 = b + 1; }
+            const u64 *Gsrc = up ? Gu : Gd;
+            u64 g = 0, pp = ~0ull;
+            for (int base = 0; base < a1 - a0; base += 8) {
+                u64 gv[8], pv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int n = base + q;
+                    const int a = up ? a1 - 1 - n : a0 + n;
+                    const bool ok = n < a1 - a0;
+                    gv[q] = ok ? __hip_atomic_load(&Gsrc[(size_t)a * wx + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    pv[q] = ok ? P[(size_t)a * wx + w] : ~0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) { g = gv[q] | (pv[q] & g); pp &= pv[q]; }
+            }
+            fold_g[(up * FB_FOLD + j) * wx + w] = g;
+            fold_p[(up * FB_FOLD + j) * wx + w] = pp;
+        }
+        __syncthreads();
+        for (int w = tid; w < wx; w += FB_THREADS) {
+            u64 c = 0;
+            for (int j = 0; j < FB_FOLD; j++) c = fold_g[j * wx + w] | (fold_p[j * wx + w] & c);
+            u64 add = c & F[w] & ~R[w];
+            if (add) { R[w] |= add; got = 1; }
+            c = 0;
+            for (int j = FB_FOLD - 1; j >= 0; j--) c = fold_g[(FB_FOLD + j) * wx + w] | (fold_p[(FB_FOLD + j) * wx + w] & c);
+            add = c & F[(rows - 1) * wx + w] & ~R[(rows - 1) * wx + w];
+            if (add) { R[(rows - 1) * wx + w] |= add; got = 1; }
+        }
+        if (got) s_chg = 1;
+        __syncthreads();
+        const int fresh = s_chg;
+        __syncthreads();
+        if (fresh) {
+            fb_converge(R, F, rows, wx, &s_chg);
+            for (int w = tid; w < wx; w += FB_THREADS) {
+                __hip_atomic_store(&Gd[(size_t)b * wx + w], R[(rows - 1) * wx + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&Gu[(size_t)b * wx + w], R[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // round g's flag word (reused four rounds later, when every workgroup is long past reading it)
+            if (tid == 0) __hip_atomic_store(&ctrl[4 + (g & 3)], (u64)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!fb_barrier(&ctrl[0], (u64)nb * ++k)) { if (tid == 0) ctrl[2] = 1; return; }
+        if (__hip_atomic_load(&ctrl[4 + (g & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u64)(g + 1)) break;
+    }
+    // holes = background not reached -> filled = everything not reached
+    for (int i = tid; i < rows * wx; i += FB_THREADS) {
+        const int r = i / wx, w = i - r * wx;
+        const u64 valid = (w == wx - 1) ? tailmask : ~0ull;
+        slice[(int64_t)(y0 + r) * wx + w] = ~R[i] & valid;
+    }
+}
+
+// bands for a slice of ny rows x wx words: rows per band and their number (0: use the one-workgroup kernel)
+static inline int fill_bands_plan(int ny, int wx, int *RB_out)
+{
+    if (wx * 8 > FB_LDS_WORDS) return 0;
+    int RB = (ny + 63) / 64;                       // aim at 64 bands
+    if (RB < 8) RB = 8;
+    if (RB * wx > FB_LDS_WORDS) RB = FB_LDS_WORDS / wx;
+    int nb = (ny + RB - 1) / RB;
+    if (nb > FB_MAX_BANDS) return 0;
+    *RB_out = RB;
+    return nb;
+}
+
+static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u64 *scratch, hipStream_t st)
+{
+    int RB = 0;
+    const int nb = getenv("TOMO_FILL_ONE_BLOCK") ? 0 : fill_bands_plan(ny, wx, &RB);
+    const int nsl = sliceB ? 2 : 1;
+    // scratch holds ny * wx + 8 words (the one-workgroup kernel's reach set): room for 16 control + 2 * 3 * nb * wx words?
+    if (nb == 0 || 16 + (int64_t)nsl * 3 * nb * wx > (int64_t)ny * wx + 8) {
+        hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceA, scratch, ny, nx, wx);
+        if (sliceB) hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceB, scratch, ny, nx, wx);
+        return tomo_status();
+    }
+    if (hipMemsetAsync(scratch, 0, 16 * sizeof(u64), st) != hipSuccess) return TOMO_E_LAUNCH;
+    FillBands p;
+    p.slice[0] = sliceA; p.slice[1] = sliceB ? sliceB : sliceA;
+    p.ctrl = scratch; p.comp = scratch + 16;
+    p.ny = ny; p.nx = nx; p.wx = wx; p.RB = RB; p.nb = nb;
+    hipLaunchKernelGGL(fill_holes_bands_kernel, dim3((unsigned)nb, (unsigned)nsl), dim3(FB_THREADS),
+                       ((size_t)2 * RB * wx + (size_t)4 * FB_FOLD * wx) * sizeof(u64), st, p);
+    return tomo_status();
+}
+
 TOMO_API int tomo_fill_holes_slice(uint64_t *bits, int nz, int ny, int nx, int z, uint64_t *scratch, void *stream)
 {
     if (!bits || !scratch || nz <= 0 || ny <= 0 || nx <= 0 || z < 0 || z >= nz) return TOMO_E_ARG;
     int wx = (int)tomo_words_per_row(nx);
     if (wx > FH_THREADS) return TOMO_E_SIZE;
-    u64 *slice = (u64 *)bits + (int64_t)z * ny * wx;
-    hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, (hipStream_t)stream, slice, (u64 *)scratch, ny, nx,
-                       wx);
-    return tomo_status();
+    return fill_holes_launch((u64 *)bits + (int64_t)z * ny * wx, nullptr, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream);
+}
+
+// Both end slices (0 and nz - 1) of a volume in ONE launch -- what _close_volume_ends does first (voxel_processor.py:60-68).
+TOMO_API int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream)
+{
+    if (!bits || !scratch || nz <= 0 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    int wx = (int)tomo_words_per_row(nx);
+    if (wx > FH_THREADS) return TOMO_E_SIZE;
+    u64 *first = (u64 *)bits, *last = nz > 1 ? (u64 *)bits + (int64_t)(nz - 1) * ny * wx : nullptr;
+    return fill_holes_launch(first, last, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -153,10 +153,7 @@ def close_ends(vol: BitVolume, inplace: bool = False) -> BitVolume:
     out = vol if inplace else BitVolume(vol.bits.clone(), vol.shape)
     wx = out.bits.shape[2]
     scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=vol.device)
-    _lib.check(L.tomo_fill_holes_slice(_p(out.bits), nz, ny, nx, 0, _p(scratch), _stream()), "tomo_fill_holes_slice")
-    if nz > 1:
-        _lib.check(L.tomo_fill_holes_slice(_p(out.bits), nz, ny, nx, nz - 1, _p(scratch), _stream()),
-                   "tomo_fill_holes_slice")
+    _lib.check(L.tomo_fill_holes_ends(_p(out.bits), nz, ny, nx, _p(scratch), _stream()), "tomo_fill_holes_ends")
     if nz > 2:
         ws = torch.empty(L.tomo_close_ends_workspace_words(nz, ny, nx), dtype=torch.int64, device=vol.device)
         _lib.check(L.tomo_close_ends_scan(_p(out.bits), nz, ny, nx, _p(ws), _stream()), "tomo_close_ends_scan")
