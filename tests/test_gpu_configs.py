@@ -172,6 +172,8 @@ def test_full_size_config(dev, name, tmp_path):
         assert sha(f.cpu().numpy()) == h["faces_i64_sha256"]
         assert np.isclose(area, h["surface_area"], rtol=1e-5)
         assert np.float64(volume_from_slice_counts(counts.cpu().numpy(), 1.0, 1.0, depths)) == h["voxel_volume"]
+        box = box_variable_depth(tuple(np.int64(i) for i in pipeline.bounding_box(sm)), 1.0, 1.0, depths)
+        assert all([float(x) for x in box[k]] == h["bbox"][k] for k in ("x", "y", "z", "dimensions"))
     del created
     gc.collect()
     # (ii) Z-slab job, rank threads on this card: bytes-equal to the single-GPU result
