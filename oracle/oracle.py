@@ -32,7 +32,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        L = ctypes.CDLL(os.environ.get("TOMO_ORACLE_LIB") or build())      # TOMO_ORACLE_LIB: the sanitizer build (make asan)
         u8p = ctypes.POINTER(ctypes.c_uint8)
         L.orc_fill_holes_2d.argtypes = [u8p, u8p, ctypes.c_int, ctypes.c_int]
         L.orc_close_ends.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -176,3 +176,46 @@ def test_create_voxel_data_input_forms(dev):
         VoxelProcessor().create_voxel_data([v[0], v[1][:-1]], True, 0, 2, 0)
     with pytest.raises(ValueError, match="Load masks first, hmm."):
         VoxelProcessor().create_voxel_data([], True)
+
+
+def test_repeated_calls_reuse_the_device_result(dev):
+    """the orchestrator repeats smooth_voxel_data / extract_manifold_surface with the same arguments
+    (tomography_3d_reconstruction.py:201-243).  The device result is remembered; every call still returns FRESH, equal
+    host arrays; other parameters or another volume never get a remembered result."""
+    from tomography_3d_reconstructor_amd import _memo
+    _memo.clear()
+    nz, ny, nx = 40, 64, 72
+    rng = np.random.default_rng(4)
+    v = np.stack(O.ellipsoid_masks(nz, ny, nx)) ^ (rng.random((nz, ny, nx)) < 0.004)
+    depths = np.full(nz, 0.3)
+    vp, se = VoxelProcessor(), SurfaceExtractor()
+    with contextlib.redirect_stdout(io.StringIO()):
+        vol = vp.create_voxel_data(list(v), True, 0, nz, 0)
+        h0 = dict(_memo.STATS)
+        sms = [vp.smooth_voxel_data(vol, iterations=3, create_manifold=True) for _ in range(3)]
+        assert _memo.STATS["hit"] == h0["hit"] + 2
+        assert all(np.array_equal(s, sms[0]) for s in sms) and len({id(s) for s in sms}) == 3
+        assert np.array_equal(sms[0], O.smooth(vol, 3, True))
+        other = vp.smooth_voxel_data(vol, iterations=2, create_manifold=True)               # other parameters: computed
+        assert np.array_equal(other, O.smooth(vol, 2, True))
+        h1 = dict(_memo.STATS)
+        meshes = [se.extract_manifold_surface(s, depths, 0.7, 0.9) for s in sms]              # three arrays, ONE device volume
+        assert _memo.STATS["hit"] == h1["hit"] + 2
+        ref = O.SurfaceExtractor().extract_manifold_surface(sms[0].copy(), depths, 0.7, 0.9)
+        for m in meshes:
+            assert m[0].tobytes() == ref[0].tobytes() and np.array_equal(m[1], ref[1])
+        assert meshes[0][0] is not meshes[1][0] and meshes[0][0].flags.writeable
+        meshes[0][0][:] = 0                                                                   # a caller scribbling on ITS copy ...
+        again = se.extract_manifold_surface(sms[2], depths, 0.7, 0.9)
+        assert again[0].tobytes() == ref[0].tobytes()                                         # ... changes nobody else's
+        m2 = se.extract_manifold_surface(sms[0], depths, 0.7, 0.8)                            # other pixel size: computed
+        ref2 = O.SurfaceExtractor().extract_manifold_surface(sms[0].copy(), depths, 0.7, 0.8)
+        assert m2[0].tobytes() == ref2[0].tobytes()
+        edited = sms[0].copy()
+        edited[20, 30, 30:40] ^= True                                                         # another volume: computed
+        m3 = se.extract_manifold_surface(edited, depths, 0.7, 0.9)
+        ref3 = O.SurfaceExtractor().extract_manifold_surface(edited.copy(), depths, 0.7, 0.9)
+        assert m3[0].tobytes() == ref3[0].tobytes() and np.array_equal(m3[1], ref3[1])
+        empty = np.zeros((6, 8, 8), bool)
+        assert se.extract_manifold_surface(empty, np.full(6, 1.0), 1.0, 1.0) is None
+    _memo.clear()

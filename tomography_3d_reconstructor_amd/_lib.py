@@ -113,7 +113,10 @@ def lib():
             raise TomoUnavailable("libtomo_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C tomography_3d_reconstructor_amd/csrc` (there is no CPU fallback)")
         L = ctypes.CDLL(SO_PATH)
+        host_only = os.environ.get("TOMO_HOST_ONLY", "0") not in ("", "0")      # the sanitizer build holds the host entry points only
         for name, (res, args) in SIGNATURES.items():
+            if host_only and not hasattr(L, name):
+                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import pipeline
+from . import _memo, pipeline
 from .voxel_processor import _device, to_device_volume, to_host_array
 
 
@@ -30,8 +30,13 @@ class SurfaceExtractor:
         missing GPU / library raises: that is not a property of the input."""
         try:
             vol = to_device_volume(volume_data)
-            res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
+            key = (np.ascontiguousarray(slice_depths, dtype=np.float64).tobytes(), float(np.float32(mm_per_pixel_y)),
+                   float(np.float32(mm_per_pixel_x)), bool(manifold), bool(add_padding))
+            res = _memo.surfaces.get(vol, key)               # device tensors of an identical earlier call (see _memo)
             if res is None:
+                res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
+                _memo.surfaces.put(vol, key, res if res is not None else "none")
+            if res is None or isinstance(res, str):
                 return None
             verts, faces = res
             vertices = to_host_array(verts.contiguous())

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-from . import _devcache, pipeline
+from . import _devcache, _memo, pipeline
 
 
 def _device():
@@ -145,7 +145,14 @@ class VoxelProcessor:
         on the first attempt (there is no CPU path to fall back to)."""
         vol = to_device_volume(voxel_data)
         try:
-            return to_host_volume(pipeline.smooth(vol, iterations, create_manifold))
+            # the orchestrator repeats this very call several times: the device result is remembered (see _memo), the
+            # host array is a fresh download every time
+            key = (int(iterations), bool(create_manifold))
+            sm = _memo.smoothed.get(vol, key)
+            if sm is None:
+                sm = pipeline.smooth(vol, iterations, create_manifold)
+                _memo.smoothed.put(vol, key, sm)
+            return to_host_volume(sm)
         except pipeline._lib.TomoUnavailable:
             raise
         except Exception as e:                                           # noqa: BLE001 -- the reference catches Exception here
