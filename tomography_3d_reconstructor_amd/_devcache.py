@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _lib
 
-_MAX = 4
+_MAX = 8          # entries hold bit-packed device volumes (1 bit per voxel); repeated results share one
 _cache = OrderedDict()
 WRITEABLE_RESULTS = os.environ.get("TOMO_WRITEABLE_RESULTS", "0") not in ("", "0")
 STATS = {"hit_readonly": 0, "hit_verified": 0, "miss_edited": 0, "miss_unverifiable": 0}
