@@ -201,6 +201,51 @@ int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int64_t pitc
                         const uint32_t *seg_aoff, const uint32_t *vox_voff, const uint8_t *vox_flags, int mode,
                         uint32_t *created, const uint32_t *base, int32_t *ft_rank, unsigned long long *totals, void *stream);
 
+/* ---------------------------------------------------------------- "mc3": marching cubes + finalisation + unique in one chain
+ * The production path for manifold=True (surface_extractor.py:55-72): same inputs as above (sign records -> tomo_mc_classify
+ * -> seg_cnt / seg_act), then
+ *   tomo_mc3_list      block sums of seg_cnt, one single-workgroup scan, list of active voxels; tot[0] = list length
+ *   tomo_mc3_eval      one float64 evaluation per active voxel: MC33 tiling reference, vertex flags, vertex coordinates
+ *                      along the owned edges (float32), counts reduced per block of 256 entries
+ *   tomo_mc3_scan      single workgroup: block prefixes, totals (tot[1] vertices, tot[2] triangles), per-slice tables and
+ *                      the 2 Nz + 1 bucket offsets of the sort (slice_tab: tomo_mc3_slice_table_words(Nz) uint32)
+ *   tomo_mc3_vertices  FINAL vertex rows (-1 shift, slice-depth map, y / x scale: surface_extractor.py:57-65, :82-113) as
+ *                      16-byte records {z', y', x', id}, partitioned per slice into in-plane / between-plane buckets,
+ *                      with their 32-bit sort keys; vertex id = 4 * (list position of the owner voxel) + slot
+ *   tomo_mc3_sort_rank segmented sort inside the buckets + gather: uniq rows in np.unique's order, table[id] = index;
+ *                      tot[4] counts the places where the rows do not ascend strictly (0 <=> the result is exact)
+ *   tomo_mc3_faces     final int64 triangles (reference order and winding) through table; tot[5] degenerate triangles
+ *                      (the caller drops them), tot[6] corners without vertex (must stay 0)
+ * Every kernel takes the list length / totals from `tot` (device uint64[8]): the chain can be enqueued into buffers sized
+ * from a hint (cap list entries, cap_v vertices, cap_f triangles) before any count is known to the host; what does not fit
+ * is flagged in tot[3] (1 list, 2 vertices, 4 triangles) and nothing is written past a buffer.
+ * Buffers: seg_blk uint32[ceil(nseg / 256)], seg_aoff uint32[nseg + 1], vox_key uint64[cap], vox_loc uint32[cap],
+ * vox_til int32[cap], vox_flags uint8[cap], vox_used uint16[cap] (cube edges with a vertex), vox_f3 / vox_c3 float[3 cap], blk3 uint32[3 ceil(cap / 256)],
+ * vrec float[4 cap_v], keys / idx uint32[cap_v], uniq float[3 cap_v], table int32[4 cap], faces int64[3 cap_f]. */
+int tomo_mc3_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_cnt, const unsigned long long *seg_act,
+                  uint32_t *seg_blk, uint32_t *seg_aoff, unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
+                  void *stream);
+int tomo_mc3_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                  const unsigned long long *vox_key, int64_t cap, const unsigned long long *tot, int z_offset,
+                  uint32_t *vox_loc, int32_t *vox_til, uint8_t *vox_flags, uint16_t *vox_used, float *vox_f3, float *vox_c3,
+                  uint32_t *blk3, void *stream);
+int64_t tomo_mc3_slice_table_words(int Nz);
+int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const uint32_t *vox_loc, int64_t cap,
+                  uint32_t *blk3, uint32_t *slice_tab, unsigned long long *tot, int64_t cap_v, int64_t cap_f, void *stream);
+int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,
+                      const unsigned long long *tot, const uint32_t *vox_loc, const uint8_t *vox_flags, const float *vox_f3,
+                      const float *vox_c3, const uint32_t *blk3, const uint32_t *slice_tab, int z_offset, int shift,
+                      const double *cum, int64_t ncum, const double *adj, int64_t nadj, float mm_y, float mm_x, float *vrec,
+                      uint32_t *keys, uint32_t *idx, void *stream);
+int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v);
+int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+                       unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
+                       void *stream);
+int tomo_mc3_faces(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
+                   const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,
+                   const uint16_t *vox_used, const uint32_t *blk3, const int32_t *table, int64_t *faces, int64_t cap_f,
+                   void *stream);
+
 /* ---------------------------------------------------------------- mesh finalisation */
 /* surface_extractor.py:57-65 + :82-113 on (V,3) float32 rows in place: -1 shift (if shift),
  * variable slice depth map of z (cum/adj float64 tables as the reference builds them; nadj = 0

@@ -440,6 +440,7 @@ def test_device_failures_return_none_like_the_reference(dev, monkeypatch, capsys
     with monkeypatch.context() as m:                     # (1) active-voxel list beyond the 32-bit index range
         m.setattr(pipeline, "LIST_LIMIT", 16)
         pipeline._NA_HINT.clear()
+        pipeline._MC3_HINT.clear()
         assert se.extract_manifold_surface(v, depths, 1.0, 1.0) is None
     with monkeypatch.context() as m:                     # (2) vertex / triangle totals beyond it
         m.setattr(pipeline, "MESH_LIMIT", 16)
@@ -448,7 +449,7 @@ def test_device_failures_return_none_like_the_reference(dev, monkeypatch, capsys
 
         def boom(*a, **k):
             raise _lib.TomoError("internal error: 3 triangle corners reference a missing vertex")
-        m.setattr(pipeline, "ensure_manifold_mesh", boom)
+        m.setattr(pipeline, "mc3_vertices" if pipeline.MC3 else "ensure_manifold_mesh", boom)
         assert se.extract_manifold_surface(v, depths, 1.0, 1.0) is None
     with monkeypatch.context() as m:                     # (4) a failing launch (status from the C ABI)
         m.setattr(pipeline._lib, "check", lambda code, what: (_ for _ in ()).throw(_lib.TomoError(what + " failed")))
@@ -828,5 +829,9 @@ def test_one_sort_unique_with_clamped_first_slice(dev, kind):
     assert gv.shape == ref[0].shape and np.array_equal(gv.view(np.int32), np.ascontiguousarray(ref[0]).view(np.int32))
     assert np.array_equal(gf, ref[1])
     if kind != "noise_first":                     # (noise may break the one-sort order elsewhere: float32 ties between buckets)
-        assert pipeline.COUNTERS["unique_one_sort"] - c0["unique_one_sort"] == 1
-        assert pipeline.COUNTERS["unique_fallback"] - c0["unique_fallback"] == 0
+        if pipeline.MC3:
+            assert pipeline.COUNTERS.get("mc3_exact", 0) - c0.get("mc3_exact", 0) == 1
+            assert pipeline.COUNTERS.get("mc3_general_unique", 0) - c0.get("mc3_general_unique", 0) == 0
+        else:
+            assert pipeline.COUNTERS["unique_one_sort"] - c0["unique_one_sort"] == 1
+            assert pipeline.COUNTERS["unique_fallback"] - c0["unique_fallback"] == 0

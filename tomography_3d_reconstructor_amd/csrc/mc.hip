@@ -749,3 +749,548 @@ TOMO_API int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int
                        (u64 *)totals);
     return tomo_status();
 }
+
+// ==========================================================================================================
+// "mc3": the same marching cubes with the mesh stages folded in (surface_extractor.py:55-72 in one chain).
+//
+//   list  -> eval -> scan -> vertices -> [segmented sort + rank: mesh.hip] -> faces
+//
+// What changes against passes 2-4 above, and why (1024^3 ellipsoid, rocprofv3: 810 us for MC + finalize + unique +
+// remap before; the device-wide scans alone were 190 us of it, the unique stage 255 us):
+//   * no device-wide scan primitive anywhere: counts are reduced per block of 256 entries by the kernel that produces or
+//     consumes them, ONE small single-block kernel scans the block sums, and the consumers add block base + local prefix;
+//   * eval does all float64 work of a cell once: MC33 tiling (a 4-byte reference to the tiling row is kept, so nothing
+//     re-evaluates it), the vertex flags and the vertex positions along the owned edges (staged as float32, 12 B/voxel);
+//   * vertices are written FINALISED (-1 shift, slice-depth map, y/x scale: surface_extractor.py:57-65, :82-113) and
+//     already PARTITIONED the way np.unique's order needs them -- per slice: the in-plane vertices (x / y edges), then
+//     the vertices between this plane and the next (z edges, cell centres) -- each with its 32-bit sort key (y' in a
+//     plane, z' between planes).  What remains of np.unique(axis=0) is one segmented sort inside the 2 Nz buckets and one
+//     gather that checks the result is STRICTLY ascending (no duplicates, no rounding coincidence): then the sorted
+//     position IS the final index.  Anything else is counted and the caller redoes the stage with the general sort;
+//   * a vertex is named by (list position of its owner voxel, slot): id = 4 pos + slot.  A triangle corner therefore
+//     needs the owner's list position only (segment offset + ballot rank: two loads in flight together) and ONE gather
+//     from the table id -> final index; faces are written once, as final int64 triples, after the sort.
+// Everything reads the list length / totals from device memory (`tot`), so the whole chain can be enqueued into buffers
+// sized from a hint before any count has come back to the host; overflows are flagged in tot[3], nothing is written
+// past a buffer.
+//
+// tot (device uint64[8]): [0] active voxels (list length)  [1] vertices  [2] triangles  [3] overflow flags (1 list,
+// 2 vertices, 4 triangles)  [4] places where the sorted rows do not ascend strictly  [5] degenerate triangles
+// [6] triangle corners without vertex (internal consistency, must stay 0)
+#define MC3_BLK 256
+#define MC3_LOC_A(l) ((l) & 1023u)
+#define MC3_LOC_B(l) (((l) >> 10) & 1023u)
+#define MC3_LOC_T(l) ((l) >> 20)
+
+// ---- sums of seg_cnt per block of 256 segments: one wave per block of segments, 16 B per lane
+__global__ __launch_bounds__(256) void mc3_segsum_kernel(const u32 *__restrict__ seg_cnt, int64_t nseg, u32 *__restrict__ seg_blk,
+                                                         int64_t nblk)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const int64_t i0 = b * MC3_BLK + lane * 4;
+    u32 s = 0;
+    if (i0 + 3 < nseg) {
+        const uint4 v = *(const uint4 *)(seg_cnt + i0);
+        s = v.x + v.y + v.z + v.w;
+    } else {
+        for (int k = 0; k < 4; k++) if (i0 + k < nseg) s += seg_cnt[i0 + k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) seg_blk[b] = s;
+}
+
+// ---- exclusive scan, in place, of K u32 arrays of n entries (a[k * stride + i]) by ONE workgroup of 1024 threads
+// (n = a few 10^4: block sums); total[k] = sum of array k.  8 consecutive entries per thread and round (two 16-byte loads),
+// wave scans, one more wave scan across the 16 wave totals.
+template <int K>
+__device__ static inline void scan_small_inplace(u32 *__restrict__ a, int64_t stride, int64_t n, u32 *total_out, u32 *lds /* K * 16 + K */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 carry[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) carry[k] = 0;
+    for (int64_t base = 0; base < n; base += 1024 * 8) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 8;
+        u32 v[K][8], s[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            u32 *p = a + k * stride + i0;
+            if (i0 + 7 < n && ((uintptr_t)p & 15) == 0) {
+                const uint4 lo = *(const uint4 *)p, hi = *(const uint4 *)(p + 4);
+                v[k][0] = lo.x; v[k][1] = lo.y; v[k][2] = lo.z; v[k][3] = lo.w; v[k][4] = hi.x; v[k][5] = hi.y; v[k][6] = hi.z; v[k][7] = hi.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[k][j] = i0 + j < n ? p[j] : 0u;
+            }
+            s[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[k] += v[k][j];
+        }
+        u32 inc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            inc[k] = wave_inclusive_scan(s[k]);
+            if (lane == 63) lds[k * 16 + w] = inc[k];
+        }
+        __syncthreads();
+        if (w == 0) {                                             // the 16 wave totals of every array: one more wave scan
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const u32 t = lane < 16 ? lds[k * 16 + lane] : 0u;
+                const u32 ti = wave_inclusive_scan(t);
+                if (lane < 16) lds[k * 16 + lane] = ti - t;
+                if (lane == 15) lds[K * 16 + k] = ti;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            u32 ex = carry[k] + lds[k * 16 + w] + inc[k] - s[k];
+            u32 *p = a + k * stride + i0;
+            if (i0 + 7 < n && ((uintptr_t)p & 15) == 0) {
+                uint4 lo, hi;
+                lo.x = ex; ex += v[k][0]; lo.y = ex; ex += v[k][1]; lo.z = ex; ex += v[k][2]; lo.w = ex; ex += v[k][3];
+                hi.x = ex; ex += v[k][4]; hi.y = ex; ex += v[k][5]; hi.z = ex; ex += v[k][6]; hi.w = ex;
+                *(uint4 *)p = lo; *(uint4 *)(p + 4) = hi;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { if (i0 + j < n) p[j] = ex; ex += v[k][j]; }
+            }
+            carry[k] += lds[K * 16 + k];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) total_out[k] = carry[k];
+}
+
+__global__ __launch_bounds__(1024) void mc3_scan_seg_kernel(u32 *__restrict__ seg_blk, int64_t nblk, u64 *__restrict__ tot)
+{
+    __shared__ u32 lds[17];
+    u32 total;
+    scan_small_inplace<1>(seg_blk, 0, nblk, &total, lds);
+    if (threadIdx.x == 0) {
+        tot[0] = total;
+        tot[1] = tot[2] = tot[3] = tot[4] = tot[5] = tot[6] = tot[7] = 0ull;
+    }
+}
+
+// ---- list: as mc_list_kernel, but the segment's offset comes from its block's base plus the prefix inside the block;
+// seg_aoff (nseg + 1 entries) is written here for the lookups of the faces pass
+__global__ __launch_bounds__(MC3_BLK) void mc3_list_kernel(const McGrid g, const u32 *__restrict__ seg_cnt,
+                                                           const u32 *__restrict__ seg_blk, const u64 *__restrict__ seg_act,
+                                                           int64_t nseg, u32 *__restrict__ seg_aoff, u64 *__restrict__ vox_key,
+                                                           u32 cap, u64 *__restrict__ tot)
+{
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t seg = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
+    const u32 cnt = seg < nseg ? seg_cnt[seg] : 0u;
+    const u32 inc = wave_inclusive_scan(cnt);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 o = seg_blk[blockIdx.x] + inc - cnt;
+    for (int k = 0; k < w; k++) o += wsum[k];
+    if (seg >= nseg) return;
+    seg_aoff[seg] = o;
+    if (seg == nseg - 1) seg_aoff[nseg] = o + cnt;
+    if (cnt == 0) return;                                       // empty: its ballot record was never written
+    if (o + cnt > cap) { if (o <= cap) atomicOr((unsigned long long *)&tot[3], 1ull); return; }   // the list does not fit: flagged, nothing written
+    const int s = (int)(seg % g.segs_per_row);
+    const int64_t row = seg / g.segs_per_row;
+    const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
+    const ulonglong2 lo = q[0], hi = q[1];
+    const u64 b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
+    const int Xs = s * SEG - SEG_SHIFT - g.xorg;
+    u64 any = b0 | b1 | b2 | b3;
+    while (any) {
+        const int L = __ffsll((long long)any) - 1;
+        any &= any - 1;
+        const int X0 = Xs + 4 * L;
+        if ((b0 >> L) & 1ull) vox_key[o++] = make_key(row, X0, 0);
+        if ((b1 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 1, 0);
+        if ((b2 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 2, 0);
+        if ((b3 >> L) & 1ull) vox_key[o++] = make_key(row, X0 + 3, 0);
+    }
+}
+
+TOMO_API int tomo_mc3_list(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_cnt, const unsigned long long *seg_act,
+                           uint32_t *seg_blk, uint32_t *seg_aoff, unsigned long long *vox_key, int64_t cap,
+                           unsigned long long *tot, void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_cnt || !seg_act || !seg_blk || !seg_aoff || !vox_key || !tot) return TOMO_E_ARG;
+    if (cap <= 0 || cap >= 0x1fffffffll) return TOMO_E_SIZE;        // ids are 4 * position + slot in a signed 32-bit index
+    if (Nx >= (1 << KEY_XBITS)) return TOMO_E_SIZE;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    const int64_t nseg = (int64_t)Nz * Ny * g.segs_per_row, nblk = ceil_div64(nseg, MC3_BLK);
+    if (nblk > 0x7fffffff) return TOMO_E_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mc3_segsum_kernel, dim3((unsigned)ceil_div64(nblk, 4)), dim3(256), 0, s, seg_cnt, nseg, seg_blk, nblk);
+    hipLaunchKernelGGL(mc3_scan_seg_kernel, dim3(1), dim3(1024), 0, s, seg_blk, nblk, (u64 *)tot);
+    hipLaunchKernelGGL(mc3_list_kernel, dim3((unsigned)nblk), dim3(MC3_BLK), 0, s, g, seg_cnt, (const u32 *)seg_blk,
+                       (const u64 *)seg_act, nseg, seg_aoff, (u64 *)vox_key, (u32)cap, (u64 *)tot);
+    return tomo_status();
+}
+
+// ---- eval: everything a cell needs in float64, once.  Per list entry: vox_loc = exclusive prefix INSIDE the block of
+// 256 entries of (in-plane vertices | between-plane vertices << 10 | triangles << 20); vox_til = tiling reference << 4 |
+// triangles; vox_flags; vox_f3 = the coordinate along the owned x / y / z edge as float32 (z, y, x order; garbage where
+// the flag is clear), vox_c3 = the centre vertex (written only when there is one).  blk3[3][nblk] = block sums.
+__global__ __launch_bounds__(MC3_BLK) void mc3_eval_kernel(const float *__restrict__ field, const McGrid g,
+                                                           const u64 *__restrict__ vox_key, int64_t cap,
+                                                           const u64 *__restrict__ tot, int z_offset,
+                                                           u32 *__restrict__ vox_loc, int32_t *__restrict__ vox_til,
+                                                           uint8_t *__restrict__ vox_flags, uint16_t *__restrict__ vox_used,
+                                                           float *__restrict__ vox_f3, float *__restrict__ vox_c3,
+                                                           u32 *__restrict__ blk3, int64_t nblk)
+{
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
+    const u64 na = tot[0];
+    const bool live = i < cap && (u64)i < na && na <= (u64)cap;
+    u32 packed = 0;
+    if (live) {
+        Cell c;
+        load_cell(field, g, vox_key[i], c);
+        int ntri = 0;
+        int32_t til = 0;
+        u32 used = 0;
+        if (c.cell_ok && c.index != 0 && c.index != 255) {
+            const McTiling t = mc_cell_tiling(c.v, c.index);
+            ntri = t.ntri;
+            if (t.centre) c.flags |= 8;
+            til = (int32_t)(((intptr_t)t.tris - (intptr_t)LUT_TILING1) * 16 + ntri);
+            // the cube edges that carry a vertex (every MC33 tiling uses exactly the bichromatic edges of its cube), bit 12: the
+            // centre vertex -- what the faces pass looks up, from the corner signs (a loop over the tiling row would do, but
+            // it sends the faces kernel's registers to scratch memory)
+            const int ix = c.index;
+#define BICH(a, b) ((u32)(((ix >> (a)) ^ (ix >> (b))) & 1))
+            used = BICH(0, 1) | BICH(1, 2) << 1 | BICH(2, 3) << 2 | BICH(3, 0) << 3 | BICH(4, 5) << 4 | BICH(5, 6) << 5 | BICH(6, 7) << 6 |
+                   BICH(7, 4) << 7 | BICH(0, 4) << 8 | BICH(1, 5) << 9 | BICH(2, 6) << 10 | BICH(3, 7) << 11 | (t.centre ? 1u << 12 : 0u);
+#undef BICH
+            if (ntri == 0) used = 0;
+        }
+        const int Zg = c.Z + z_offset;
+        float3u f3;
+        f3.x = (float)((double)Zg + mc_edge_offset(c.v[0], c.v[4]));
+        f3.y = (float)((double)c.Y + mc_edge_offset(c.v[0], c.v[3]));
+        f3.z = (float)((double)c.X + mc_edge_offset(c.v[0], c.v[1]));
+        *(float3u *)(vox_f3 + 3 * i) = f3;
+        if (c.flags & 8) {
+            double ox, oy, oz;
+            mc_centre_offset(c.v, &ox, &oy, &oz);
+            *(float3u *)(vox_c3 + 3 * i) = (float3u){(float)((double)Zg + oz), (float)((double)c.Y + oy), (float)((double)c.X + ox)};
+        }
+        vox_til[i] = til;
+        vox_flags[i] = (uint8_t)c.flags;
+        vox_used[i] = (uint16_t)used;
+        packed = (u32)__popc(c.flags & 3) | ((u32)__popc(c.flags & 12) << 10) | ((u32)ntri << 20);
+    }
+    const u32 inc = wave_inclusive_scan(packed);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    u32 ex = inc - packed;
+    for (int k = 0; k < w; k++) ex += wsum[k];
+    if (i < cap) vox_loc[i] = ex;
+    if (threadIdx.x == MC3_BLK - 1) {
+        const u32 sum = ex + packed;
+        blk3[blockIdx.x] = MC3_LOC_A(sum);
+        blk3[nblk + blockIdx.x] = MC3_LOC_B(sum);
+        blk3[2 * nblk + blockIdx.x] = MC3_LOC_T(sum);
+    }
+}
+
+// ---- scan: block sums -> exclusive prefixes, totals, the per-slice tables and the 2 Nz + 1 bucket offsets of the sort.
+// slice_tab: sliceA[Nz + 1] | sliceB[Nz + 1] | offsets[2 Nz + 1]  (uint32)
+__global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
+                                                        const u32 *__restrict__ vox_loc, int64_t cap, u32 *__restrict__ blk3,
+                                                        int64_t nblk, u32 *__restrict__ slice_tab, u64 *__restrict__ tot,
+                                                        int64_t cap_v, int64_t cap_f)
+{
+    __shared__ u32 lds[3 * 16 + 3];
+    u32 totals[3];
+    scan_small_inplace<3>(blk3, nblk, nblk, totals, lds);       // ends with a barrier: the prefixes are visible to every thread
+    const u64 na = tot[0];
+    const u32 totA = totals[0], totB = totals[1], totT = totals[2];
+    const int Nz = g.Nz;
+    u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1), *offsets = slice_tab + 2 * (Nz + 1);
+    const int64_t segs_per_slice = (int64_t)g.Ny * g.segs_per_row;
+    const bool fits = na <= (u64)cap;
+    for (int Z = threadIdx.x; Z <= Nz; Z += 1024) {
+        u32 a = totA, b = totB;
+        if (Z < Nz && fits) {
+            const u64 s = seg_aoff[(int64_t)Z * segs_per_slice];         // list position of the slice's first voxel
+            if (s < na) {
+                const u32 l = vox_loc[s];
+                a = blk3[s >> 8] + MC3_LOC_A(l);
+                b = blk3[nblk + (s >> 8)] + MC3_LOC_B(l);
+            }
+        }
+        sliceA[Z] = a;
+        sliceB[Z] = b;
+    }
+    __syncthreads();
+    u64 ov = 0;
+    if ((u64)totA + totB > (u64)cap_v) ov |= 2ull;
+    if ((u64)totT > (u64)cap_f) ov |= 4ull;
+    if (!fits) ov |= 1ull;
+    for (int Z = threadIdx.x; Z < Nz; Z += 1024) {           // on overflow every bucket is empty: the sort touches nothing
+        offsets[2 * Z] = ov ? 0u : sliceA[Z] + sliceB[Z];
+        offsets[2 * Z + 1] = ov ? 0u : sliceA[Z + 1] + sliceB[Z];
+    }
+    if (threadIdx.x == 0) {
+        offsets[2 * Nz] = ov ? 0u : totA + totB;
+        tot[1] = (u64)totA + totB;
+        tot[2] = totT;
+        if (ov) atomicOr((unsigned long long *)&tot[3], (unsigned long long)ov);
+    }
+}
+
+// ---- vertices: final coordinates (surface_extractor.py:57-65, :82-113 -- the arithmetic of vertex_finalize_kernel),
+// partitioned by (slice, in-plane / between), one 16-byte record {z', y', x', id} per vertex + its sort key
+struct Mc3Final {
+    const double *cum, *adj;
+    int64_t ncum, nadj;
+    int shift;
+    float mm_y, mm_x;
+};
+
+__device__ static inline void mc3_put_vertex(float z, float y, float x, u32 id, u32 dest, bool between, const Mc3Final &fin,
+                                             float4 *__restrict__ vrec, u32 *__restrict__ keys, u32 *__restrict__ idx)
+{
+    if (fin.shift) { z -= 1.0f; y -= 1.0f; x -= 1.0f; }
+    if (fin.nadj > 0) {
+        if (z < 0.0f) z = 0.0f;
+        else if ((double)z >= (double)(fin.ncum - 1)) z = (float)fin.cum[fin.ncum - 1];
+        else {
+            const int64_t lo = (int64_t)floorf(z);
+            const float frac = z - (float)lo;
+            const int64_t k = lo < fin.nadj - 1 ? lo : fin.nadj - 1;
+            z = (float)(fin.cum[lo] + (double)frac * fin.adj[k]);
+        }
+    }
+    y = y * fin.mm_y;
+    x = x * fin.mm_x;
+    vrec[dest] = make_float4(z, y, x, __uint_as_float(id));
+    const u32 u = __float_as_uint(between ? z : y);
+    keys[dest] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);         // order-preserving float -> uint (fkey32 of mesh.hip)
+    idx[dest] = dest;
+}
+
+__global__ __launch_bounds__(MC3_BLK) void mc3_vertices_kernel(const McGrid g, const u64 *__restrict__ vox_key, int64_t cap,
+                                                               const u64 *__restrict__ tot, const u32 *__restrict__ vox_loc,
+                                                               const uint8_t *__restrict__ vox_flags,
+                                                               const float *__restrict__ vox_f3, const float *__restrict__ vox_c3,
+                                                               const u32 *__restrict__ blk3, int64_t nblk,
+                                                               const u32 *__restrict__ slice_tab, int z_offset,
+                                                               const Mc3Final fin, float4 *__restrict__ vrec,
+                                                               u32 *__restrict__ keys, u32 *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
+    if (tot[3] != 0 || i >= cap || (u64)i >= tot[0]) return;
+    const int flags = vox_flags[i];
+    if (!flags) return;
+    const u64 key = vox_key[i];
+    const int64_t row = (int64_t)(key >> (KEY_XBITS + 2));
+    const int X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
+    const int Y = (int)(row % g.Ny), Z = (int)(row / g.Ny);
+    const u32 l = vox_loc[i];
+    const u32 *sliceA = slice_tab, *sliceB = slice_tab + (g.Nz + 1);
+    u32 dA = sliceB[Z] + blk3[i >> 8] + MC3_LOC_A(l);                // in-plane vertices of slice Z start at sliceA[Z] + sliceB[Z]
+    u32 dB = sliceA[Z + 1] + blk3[nblk + (i >> 8)] + MC3_LOC_B(l);   // between-plane ones after all in-plane ones of the slice
+    const float3u f3 = *(const float3u *)(vox_f3 + 3 * i);
+    const float fZ = (float)(Z + z_offset), fY = (float)Y, fX = (float)X;
+    const u32 id = (u32)i * 4u;
+    if (flags & 1) mc3_put_vertex(fZ, fY, f3.z, id, dA++, false, fin, vrec, keys, idx);
+    if (flags & 2) mc3_put_vertex(fZ, f3.y, fX, id + 1u, dA, false, fin, vrec, keys, idx);
+    if (flags & 4) mc3_put_vertex(f3.x, fY, fX, id + 2u, dB++, true, fin, vrec, keys, idx);
+    if (flags & 8) {
+        const float3u c3 = *(const float3u *)(vox_c3 + 3 * i);
+        mc3_put_vertex(c3.x, c3.y, c3.z, id + 3u, dB, true, fin, vrec, keys, idx);
+    }
+}
+
+// ---- faces: final int64 triples.  table[id] = final vertex index of vertex id = 4 * (owner's list position) + slot.
+// A block's triangles are ONE contiguous run of the face list (block base + prefix inside the block): they are staged in
+// LDS and leave as coalesced 8-byte stores (three scattered 8-byte stores per triangle cost 4x the bytes in partial-line
+// writes: 730 MB of WRITE_SIZE for 170 MB of triangles at 1024^3), in windows of MC3_FWIN triangles.
+#define MC3_FWIN 1024
+__global__ __launch_bounds__(MC3_BLK) void mc3_faces_kernel(const McGrid g, const u64 *__restrict__ vox_key, int64_t cap,
+                                                            u64 *__restrict__ tot, const u64 *__restrict__ seg_act,
+                                                            const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_loc,
+                                                            const int32_t *__restrict__ vox_til, const uint16_t *__restrict__ vox_used,
+                                                            const u32 *__restrict__ blk3, int64_t nblk,
+                                                            const int32_t *__restrict__ table, int64_t *__restrict__ faces,
+                                                            int64_t cap_f)
+{
+    __shared__ int32_t sf[3 * MC3_FWIN];
+    const int64_t i = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
+    const u64 na = tot[0];
+    if (tot[3] != 0) return;                                     // something did not fit (uniform over the grid)
+    const u64 fbase = blk3[2 * nblk + blockIdx.x];
+    const u64 fend = (int64_t)blockIdx.x + 1 < nblk ? (u64)blk3[2 * nblk + blockIdx.x + 1] : tot[2];
+    const u32 total = (u32)(fend - fbase);                       // triangles of this block
+    if (total == 0 || fend > (u64)cap_f) return;                 // (uniform over the block)
+    int ntri = 0;
+    u32 tloc = 0;
+    const signed char *tris = LUT_TILING1;
+    // final index of the vertex on each of the 13 edges (scalars on purpose: as an array with run-time conditions around
+    // its stores the compiler keeps it -- and everything indexed like it -- in scratch memory, 176 B per lane)
+    int32_t id0 = -1, id1 = -1, id2 = -1, id3 = -1, id4 = -1, id5 = -1, id6 = -1, id7 = -1, id8 = -1, id9 = -1, id10 = -1, id11 = -1,
+            id12 = -1;
+    bool bad = false;
+    if (i < cap && (u64)i < na) {
+        const int32_t til = vox_til[i];
+        ntri = til & 15;
+        tris = (const signed char *)((intptr_t)LUT_TILING1 + (intptr_t)(til >> 4));
+    }
+    if (ntri > 0) {
+        tloc = MC3_LOC_T(vox_loc[i]);
+        const u64 key = vox_key[i];
+        const int64_t row = (int64_t)(key >> (KEY_XBITS + 2));
+        const int X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
+        const int64_t rowY = (int64_t)g.Ny;
+        const u32 used = vox_used[i];
+        // owner voxels of the 13 possible vertices: this voxel (edges 0, 3, 8, centre 12), (x+1) edges 1, 9, then the five of
+        // mc_emit_kernel: (y+1) 2, 11; (z+1) 4, 7; (y+1, x+1) 10; (z+1, x+1) 5; (y+1, z+1) 6.
+        // A lookup that is not needed goes to this voxel's own key: always a valid address.
+#define MC3_USED(mask) ((used & (mask)) != 0)
+#define MC3_OWNER(n, needed, okey)                                                                                                  \
+        const bool need##n = (needed);                                                                                             \
+        const u64 k##n = need##n ? (okey) : key;                                                                                   \
+        const u32 cc##n = ((u32)(k##n >> 2) & ((1u << KEY_XBITS) - 1u)) + (u32)g.xorg + SEG_SHIFT;                                 \
+        const u64 seg##n = (k##n >> (KEY_XBITS + 2)) * (u64)g.segs_per_row + (cc##n >> 8);                                         \
+        const u32 a0_##n = seg_aoff[seg##n], a1_##n = seg_aoff[seg##n + 1];                                                        \
+        const Rec4 rec##n = load_rec(seg_act, (int64_t)seg##n);       /* garbage for an empty segment: masked below */
+        MC3_OWNER(2, MC3_USED((1u << 2) | (1u << 11)), make_key(row + 1, X, 0))
+        MC3_OWNER(3, MC3_USED((1u << 4) | (1u << 7)), make_key(row + rowY, X, 0))
+        MC3_OWNER(4, MC3_USED(1u << 10), make_key(row + 1, X + 1, 0))
+        MC3_OWNER(5, MC3_USED(1u << 5), make_key(row + rowY, X + 1, 0))
+        MC3_OWNER(6, MC3_USED(1u << 6), make_key(row + 1 + rowY, X, 0))
+#undef MC3_OWNER
+        // (x+1, y, z) is the next list entry if it is active at all
+        const int64_t inx = (u64)(i + 1) < na ? i + 1 : i;
+        const bool have1 = vox_key[inx] == key + 4ull;
+        const u32 pos0 = (u32)i, pos1 = (u32)inx;
+#define MC3_RANK(n)                                                                                                                 \
+        bool have##n;                                                                                                              \
+        u32 pos##n;                                                                                                                \
+        {                                                                                                                          \
+            const int L = (int)((cc##n & 255u) >> 2), k = (int)(cc##n & 3u);                                                       \
+            const u64 b0 = rec##n.b[0], b1 = rec##n.b[1], b2 = rec##n.b[2], b3 = rec##n.b[3];                                      \
+            const u64 bk = k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3));                                                      \
+            const u64 m = (1ull << L) - 1ull;                                                                                      \
+            u32 rank = (u32)(__popcll(b0 & m) + __popcll(b1 & m) + __popcll(b2 & m) + __popcll(b3 & m));                          \
+            rank += (k > 0 ? (u32)((b0 >> L) & 1ull) : 0u) + (k > 1 ? (u32)((b1 >> L) & 1ull) : 0u) +                             \
+                    (k > 2 ? (u32)((b2 >> L) & 1ull) : 0u);                                                                        \
+            have##n = need##n && a1_##n != a0_##n && ((bk >> L) & 1ull);                                                           \
+            pos##n = have##n ? a0_##n + rank : (u32)i;                                                                             \
+        }
+        MC3_RANK(2) MC3_RANK(3) MC3_RANK(4) MC3_RANK(5) MC3_RANK(6)
+#undef MC3_RANK
+        const bool have0 = true;
+        // edge e: owner number o, slot sl
+#define MC3_EDGE(e, o, sl)                                                                                                          \
+        if (used & (1u << e)) { if (have##o) id##e = table[(int64_t)pos##o * 4 + sl]; else bad = true; }
+        MC3_EDGE(0, 0, 0) MC3_EDGE(1, 1, 1) MC3_EDGE(2, 2, 0) MC3_EDGE(3, 0, 1) MC3_EDGE(4, 3, 0) MC3_EDGE(5, 5, 1) MC3_EDGE(6, 6, 0)
+        MC3_EDGE(7, 3, 1) MC3_EDGE(8, 0, 2) MC3_EDGE(9, 1, 2) MC3_EDGE(10, 4, 2) MC3_EDGE(11, 2, 2) MC3_EDGE(12, 0, 3)
+#undef MC3_EDGE
+#undef MC3_USED
+    }
+    int degen = 0;
+    for (u32 w0 = 0; w0 < total; w0 += MC3_FWIN) {
+        for (int tI = 0; tI < ntri; tI++) {
+            const u32 sl = tloc + (u32)tI - w0;                  // (unsigned: slots below the window wrap to huge values)
+            if (sl >= MC3_FWIN) continue;
+            int32_t tv[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int ed = tris[3 * tI + j];
+                int32_t v = id0;                                // select chain over scalars
+                v = ed == 1 ? id1 : v; v = ed == 2 ? id2 : v; v = ed == 3 ? id3 : v; v = ed == 4 ? id4 : v;
+                v = ed == 5 ? id5 : v; v = ed == 6 ? id6 : v; v = ed == 7 ? id7 : v; v = ed == 8 ? id8 : v;
+                v = ed == 9 ? id9 : v; v = ed == 10 ? id10 : v; v = ed == 11 ? id11 : v; v = ed == 12 ? id12 : v;
+                tv[j] = v;
+            }
+            sf[3 * sl] = tv[2]; sf[3 * sl + 1] = tv[1]; sf[3 * sl + 2] = tv[0];     // np.fliplr(faces) of the skimage wrapper
+            degen += (tv[0] == tv[1] || tv[1] == tv[2] || tv[0] == tv[2]) ? 1 : 0;
+        }
+        __syncthreads();
+        const u32 n = 3u * (total - w0 < MC3_FWIN ? total - w0 : (u32)MC3_FWIN);
+        int64_t *dst = faces + 3 * (int64_t)(fbase + w0);
+        for (u32 e = threadIdx.x; e < n; e += MC3_BLK) dst[e] = (int64_t)sf[e];
+        __syncthreads();
+    }
+    if (degen) atomicAdd((unsigned long long *)&tot[5], (unsigned long long)degen);
+    if (bad) atomicAdd((unsigned long long *)&tot[6], 1ull);
+}
+
+TOMO_API int tomo_mc3_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int xorg, double iso,
+                           const unsigned long long *vox_key, int64_t cap, const unsigned long long *tot, int z_offset,
+                           uint32_t *vox_loc, int32_t *vox_til, uint8_t *vox_flags, uint16_t *vox_used, float *vox_f3,
+                           float *vox_c3, uint32_t *blk3, void *stream)
+{
+    McGrid g;
+    int rc = make_grid(g, field, Nz, Ny, Nx, pitch, xorg, iso);
+    if (rc) return rc;
+    if (!vox_key || !tot || !vox_loc || !vox_til || !vox_flags || !vox_used || !vox_f3 || !vox_c3 || !blk3 || cap <= 0) return TOMO_E_ARG;
+    const int64_t nblk = ceil_div64(cap, MC3_BLK);
+    if (nblk > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc3_eval_kernel, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, field, g, (const u64 *)vox_key,
+                       cap, (const u64 *)tot, z_offset, vox_loc, vox_til, vox_flags, vox_used, vox_f3, vox_c3, blk3, nblk);
+    return tomo_status();
+}
+
+TOMO_API int64_t tomo_mc3_slice_table_words(int Nz) { return 4 * (int64_t)Nz + 8; }
+
+TOMO_API int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const uint32_t *vox_loc, int64_t cap,
+                           uint32_t *blk3, uint32_t *slice_tab, unsigned long long *tot, int64_t cap_v, int64_t cap_f,
+                           void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !seg_aoff || !vox_loc || !blk3 || !slice_tab || !tot || cap <= 0) return TOMO_E_ARG;
+    if (cap_v >= 0x7fffffffll || cap_f >= 0x7fffffffll) return TOMO_E_SIZE;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    hipLaunchKernelGGL(mc3_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, seg_aoff, vox_loc, cap, blk3,
+                       ceil_div64(cap, MC3_BLK), slice_tab, (u64 *)tot, cap_v, cap_f);
+    return tomo_status();
+}
+
+TOMO_API int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,
+                               const unsigned long long *tot, const uint32_t *vox_loc, const uint8_t *vox_flags,
+                               const float *vox_f3, const float *vox_c3, const uint32_t *blk3, const uint32_t *slice_tab,
+                               int z_offset, int shift, const double *cum, int64_t ncum, const double *adj, int64_t nadj,
+                               float mm_y, float mm_x, float *vrec, uint32_t *keys, uint32_t *idx, void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !vox_key || !tot || !vox_loc || !vox_flags || !vox_f3 || !vox_c3 || !blk3 || !slice_tab ||
+        !vrec || !keys || !idx || cap <= 0 || (nadj > 0 && (!cum || !adj || ncum != nadj + 1)))
+        return TOMO_E_ARG;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    Mc3Final fin; fin.cum = cum; fin.adj = adj; fin.ncum = ncum; fin.nadj = nadj; fin.shift = shift; fin.mm_y = mm_y; fin.mm_x = mm_x;
+    const int64_t nblk = ceil_div64(cap, MC3_BLK);
+    hipLaunchKernelGGL(mc3_vertices_kernel, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, g, (const u64 *)vox_key, cap,
+                       (const u64 *)tot, vox_loc, vox_flags, vox_f3, vox_c3, blk3, nblk, slice_tab, z_offset, fin, (float4 *)vrec,
+                       keys, idx);
+    return tomo_status();
+}
+
+TOMO_API int tomo_mc3_faces(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,
+                            unsigned long long *tot, const unsigned long long *seg_act, const uint32_t *seg_aoff,
+                            const uint32_t *vox_loc, const int32_t *vox_til, const uint16_t *vox_used, const uint32_t *blk3,
+                            const int32_t *table, int64_t *faces, int64_t cap_f, void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !vox_key || !tot || !seg_act || !seg_aoff || !vox_loc || !vox_til || !vox_used || !blk3 || !table || !faces ||
+        cap <= 0 || cap_f < 0)
+        return TOMO_E_ARG;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    const int64_t nblk = ceil_div64(cap, MC3_BLK);
+    hipLaunchKernelGGL(mc3_faces_kernel, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, g, (const u64 *)vox_key, cap,
+                       (u64 *)tot, (const u64 *)seg_act, seg_aoff, vox_loc, vox_til, vox_used, blk3, nblk, table, faces, cap_f);
+    return tomo_status();
+}

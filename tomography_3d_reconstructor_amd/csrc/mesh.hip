@@ -418,6 +418,122 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     return tomo_status();
 }
 
+// ------------------------------------------------------------------------------------------ mc3: sort + rank
+// The unique stage of the mc3 chain (mc.hip): vertices arrive FINALISED as 16-byte records {z', y', x', id}, already
+// partitioned into the 2 Nz buckets (offsets from mc3_scan_kernel) with their 32-bit sort keys.  One segmented sort
+// inside the buckets, the clamped-run merge of the first two buckets (see uq_merge_kernel), and one gather that writes
+// the rows in order, table[id] = position, and counts every place where the result does not ascend STRICTLY: with a
+// count of zero the sorted position is np.unique's index (no duplicate rows, no rounding coincidence) -- otherwise the
+// caller redoes the stage with tomo_mesh_unique on the rows.
+__device__ static inline bool rec_less(const float4 &a, const float4 &b)
+{
+    return a.x < b.x || (a.x == b.x && (a.y < b.y || (a.y == b.y && a.z < b.z)));
+}
+
+__global__ __launch_bounds__(256) void uq3_merge_kernel(const float4 *__restrict__ vrec, const u32 *__restrict__ off,
+                                                        const u32 *__restrict__ idx, u32 *__restrict__ alt)
+{
+    const u32 o1 = off[1], o2 = off[2], o3 = off[3];
+    const u32 na = o2 - o1, nb = o3 - o2;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < na + nb; t += gridDim.x * blockDim.x) {
+        const bool inA = t < na;
+        const u32 src = idx[inA ? o1 + t : o2 + (t - na)];
+        const float4 k = vrec[src];
+        const u32 base = inA ? o2 : o1;
+        u32 lo = 0, hi = inA ? nb : na;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            const float4 m = vrec[idx[base + mid]];
+            const bool less = rec_less(m, k);
+            const bool equal = m.x == k.x && m.y == k.y && m.z == k.z;
+            if (less || (!inA && equal)) lo = mid + 1; else hi = mid;      // B counts the A elements <= itself
+        }
+        alt[o1 + (inA ? t : t - na) + lo] = src;
+    }
+}
+
+__global__ __launch_bounds__(256) void uq3_rank_kernel(const float4 *__restrict__ vrec, int64_t cap_v, const UqOrder ord,
+                                                       float *__restrict__ uniq, int32_t *__restrict__ table,
+                                                       u64 *__restrict__ tot)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool viol = false;
+    const u64 nv = tot[1];
+    const bool live = tot[3] == 0 && i < cap_v && (u64)i < nv;
+    // A sort that did not yield the lexicographic order (rows tie on the key but not as rows) can leave the merged range
+    // with slots the merge never wrote: whatever they hold must not be used as an index.  Such a slot -- or a stale one
+    // that repeats an element -- always shows up as a place where the rows do not ascend strictly.
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        u32 sa = ord.at((u32)i);
+        if ((u64)sa >= nv) { sa = 0; viol = true; }
+        a = vrec[sa];
+    }
+    // the predecessor's row is the neighbouring lane's own row (one gather per element instead of two); lane 0 fetches it
+    float4 b;
+    b.x = __shfl_up(a.x, 1, 64); b.y = __shfl_up(a.y, 1, 64); b.z = __shfl_up(a.z, 1, 64);
+    if (live) {
+        if ((threadIdx.x & 63) == 0 && i > 0) {
+            u32 sb = ord.at((u32)i - 1u);
+            if ((u64)sb >= nv) { sb = 0; viol = true; }
+            b = vrec[sb];
+        }
+        if (i > 0) viol = viol || !rec_less(b, a);
+        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));      // one 12-byte store per row
+        *(f3u *)(uniq + 3 * i) = (f3u){a.x, a.y, a.z};
+        table[__float_as_uint(a.w)] = (int32_t)i;
+    }
+    const u64 n = (u64)__popcll(__ballot(viol));
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd((unsigned long long *)&tot[4], (unsigned long long)n);
+}
+
+struct Uq3Layout { size_t keys_alt, idx_alt, idx_merge, temp, temp_bytes, total; };
+
+static Uq3Layout uq3_layout(int64_t cap_v)
+{
+    Uq3Layout L;
+    size_t n = (size_t)(cap_v > 0 ? cap_v : 1), off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.keys_alt = take(n * 4); L.idx_alt = take(n * 4); L.idx_merge = take(n * 4);
+    size_t t = 0;
+    (void)rocprim::segmented_radix_sort_pairs<UqSegCfg>(nullptr, t, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
+                                                        (unsigned)n, (unsigned)(2 * UQ_MAX_SLABS), (const u32 *)nullptr,
+                                                        (const u32 *)nullptr, 0, 32, (hipStream_t)0);
+    L.temp_bytes = t;
+    L.temp = take(t + 256);
+    L.total = off;
+    return L;
+}
+
+TOMO_API int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v) { return (int64_t)uq3_layout(cap_v).total; }
+
+TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+                                unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
+                                void *stream)
+{
+    if (!vrec || !keys || !idx || !slice_tab || !tot || !uniq || !table || !workspace || cap_v <= 0 || Nz < 1) return TOMO_E_ARG;
+    if (cap_v >= 0x7fffffffll || Nz > UQ_MAX_SLABS) return TOMO_E_SIZE;
+    Uq3Layout L = uq3_layout(cap_v);
+    if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
+    char *ws = (char *)workspace;
+    u32 *keys_alt = (u32 *)(ws + L.keys_alt), *idx_alt = (u32 *)(ws + L.idx_alt), *idx_merge = (u32 *)(ws + L.idx_merge);
+    const u32 *offsets = slice_tab + 2 * ((int64_t)Nz + 1);
+    hipStream_t s = (hipStream_t)stream;
+    size_t tb = L.temp_bytes;
+    if (rocprim::segmented_radix_sort_pairs<UqSegCfg>(ws + L.temp, tb, keys, keys_alt, idx, idx_alt, (unsigned)cap_v, (unsigned)(2 * Nz),
+                                                      offsets, offsets + 1, 0, 32, s) != hipSuccess)
+        return TOMO_E_LAUNCH;
+    UqOrder order{(const u32 *)idx_alt, nullptr, nullptr};
+    if (Nz >= 2) {
+        hipLaunchKernelGGL(uq3_merge_kernel, dim3(256), dim3(256), 0, s, (const float4 *)vrec, offsets, (const u32 *)idx_alt, idx_merge);
+        order.alt = idx_merge;
+        order.off = offsets;
+    }
+    hipLaunchKernelGGL(uq3_rank_kernel, dim3((unsigned)ceil_div64(cap_v, 256)), dim3(256), 0, s, (const float4 *)vrec, cap_v, order,
+                       uniq, table, (u64 *)tot);
+    return tomo_status();
+}
+
 // ------------------------------------------------------------------------------------------ lookup
 // Index of every query row in a lexicographically sorted, duplicate-free (U,3) row list (binary search); a row that is
 // not there gets -1 and is counted in *missing.  The Z-slab job uses it to number the few thousand shared-plane vertices

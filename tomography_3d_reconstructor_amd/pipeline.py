@@ -566,6 +566,9 @@ def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x
     device tensors, or None where the reference returns None.
     """
     f = make_field(vol, manifold, add_padding, sparse=FIELD_SPARSE)
+    if manifold and MC3:
+        m = mc3_vertices(f, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding)
+        return None if m is None else (m.uniq, m.faces_final)
     mesh = marching_cubes(f, 0.5)
     if mesh is None:
         return None
@@ -578,6 +581,188 @@ def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x
     del f
     finalize_vertices(mesh.vpos, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
     return ensure_manifold_mesh(mesh)
+
+
+# ----------------------------------------------------------------------------- mc3: marching cubes + finalise + unique, one chain
+MC3 = os.environ.get("TOMO_MC_PATH", "mc3") != "old"     # manifold=True surfaces through the mc3 chain (csrc/mc.hip, "mc3")
+_MC3_HINT = {}          # field geometry -> (active voxels, vertices, triangles) of the last surface of that geometry
+_PINNED_TOT = {}
+
+
+def _download_tot(tot):
+    """The 8 counters of a chain in ONE transfer into page-locked memory (no pageable bounce buffer, no extra blit)."""
+    key = str(tot.device)
+    host = _PINNED_TOT.get(key)
+    if host is None:
+        host = _PINNED_TOT[key] = torch.empty(8, dtype=torch.int64, pin_memory=True)
+    host.copy_(tot, non_blocking=True)
+    torch.cuda.current_stream(tot.device).synchronize()
+    return [int(x) for x in host]
+
+
+class Mc3Surface:
+    """Vertices of a surface through the mc3 chain, ready for its triangles: `uniq` (U,3) float32 final rows in np.unique's
+    order, `table` int32 (vertex id -> row index; id = 4 * list position of the owner voxel + slot).  faces(table) writes the
+    final int64 triangles through any such table (a Z-slab rank passes GLOBAL indices)."""
+
+    def __init__(self):
+        self.uniq = self.table = None
+        self.nv = self.nf = self.na = 0
+
+    def faces(self, table=None, again=False):
+        L = _lib.lib()
+        f, st = self._f, _stream()
+        tab = self.table if table is None else table
+        if tab.dtype != torch.int32 or tab.numel() < 4 * self._cap:
+            raise ValueError("table must be int32 with 4 entries per list position")
+        if again:
+            self._tot[5:7].zero_()                               # the counters of an earlier faces pass
+        faces = torch.empty((max(self._cap_f, 1), 3), dtype=torch.int64, device=tab.device)
+        _lib.check(L.tomo_mc3_faces(f.Nz, f.Ny, f.Nx, f.xorg, _p(self._vox_key), self._cap, _p(self._tot), _p(self._seg_act),
+                                    _p(self._seg_aoff), _p(self._vox_loc), _p(self._vox_til), _p(self._vox_used), _p(self._blk3), _p(tab), _p(faces),
+                                    self._cap_f, st), "tomo_mc3_faces")
+        return faces
+
+
+def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding=True, z_offset=0, with_faces=True):
+    """surface_extractor.py:55-65 + :82-113 + the vertex half of :115-126 for a manifold=True field at level 0.5.
+    -> Mc3Surface (its .faces_final holds the triangles when with_faces), or None where the reference returns None."""
+    L = _lib.lib()
+    if min(f.Nz, f.Ny, f.Nx) < 2:
+        return None
+    if f.signs is None or f.signs_level != 0.5:
+        if getattr(f, "sparse", False):
+            raise _lib.TomoError("a sparse field holds floats only near the 0.5 surface")
+        field_signs(f, 0.5)
+    dev, st = f.data.device, _stream()
+    geo = (f.Nz, f.Ny, f.Nx, f.pitch, f.xorg, 0.5)
+    spr = L.tomo_mc_segments_per_row(f.Nx, f.xorg)
+    nseg = f.Nz * f.Ny * spr
+    seg_act = torch.empty(nseg * 4, dtype=torch.int64, device=dev)
+    seg_cnt = torch.empty(nseg, dtype=torch.int32, device=dev)
+    _lib.check(L.tomo_mc_classify(_p(f.signs), _p(f.gcls), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
+    seg_blk = torch.empty((nseg + 255) // 256, dtype=torch.int32, device=dev)
+    seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    tot = torch.empty(8, dtype=torch.int64, device=dev)
+    d = np.ascontiguousarray(slice_depths, dtype=np.float64)
+    if len(d):
+        cum_t, adj_t = _depth_tables_on_device(d, add_padding, dev)
+        nadj, ncum = adj_t.shape[0], cum_t.shape[0]
+    else:
+        adj_t = cum_t = None
+        nadj = ncum = 0
+    mmy, mmx = float(np.float32(mm_per_pixel_y)), float(np.float32(mm_per_pixel_x))
+    hint_key = (f.Nz, f.Ny, f.Nx)
+    hint = _MC3_HINT.get(hint_key) if NA_HINTS else None
+    m = Mc3Surface()
+    m._f, m._seg_act, m._seg_aoff, m._tot = f, seg_act, seg_aoff, tot
+
+    def list_and_eval(cap):
+        m._cap = cap
+        m._vox_key = torch.empty(cap, dtype=torch.int64, device=dev)
+        _lib.check(L.tomo_mc3_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_cnt), _p(seg_act), _p(seg_blk), _p(seg_aoff), _p(m._vox_key), cap,
+                                   _p(tot), st), "tomo_mc3_list")
+
+    def eval_scan(cap, cap_v, cap_f):
+        nblk = (cap + 255) // 256
+        m._vox_loc = torch.empty(cap, dtype=torch.int32, device=dev)
+        m._vox_til = torch.empty(cap, dtype=torch.int32, device=dev)
+        m._vox_flags = torch.empty(cap, dtype=torch.uint8, device=dev)
+        m._vox_used = torch.empty(cap, dtype=torch.int16, device=dev)
+        m._vox_f3 = torch.empty(3 * cap, dtype=torch.float32, device=dev)
+        m._vox_c3 = torch.empty(3 * cap, dtype=torch.float32, device=dev)
+        m._blk3 = torch.empty(3 * nblk, dtype=torch.int32, device=dev)
+        m._slice_tab = torch.empty(L.tomo_mc3_slice_table_words(f.Nz), dtype=torch.int32, device=dev)
+        _lib.check(L.tomo_mc3_eval(_p(f.data), *geo, _p(m._vox_key), cap, _p(tot), int(z_offset), _p(m._vox_loc), _p(m._vox_til),
+                                   _p(m._vox_flags), _p(m._vox_used), _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), st), "tomo_mc3_eval")
+        _lib.check(L.tomo_mc3_scan(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(m._vox_loc), cap, _p(m._blk3), _p(m._slice_tab), _p(tot),
+                                   cap_v, cap_f, st), "tomo_mc3_scan")
+
+    def vertices_sort(cap, cap_v):
+        m._vrec = torch.empty((cap_v, 4), dtype=torch.float32, device=dev)
+        keys = torch.empty(cap_v, dtype=torch.int32, device=dev)
+        idx = torch.empty(cap_v, dtype=torch.int32, device=dev)
+        m._uniq = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
+        m.table = torch.empty(4 * cap, dtype=torch.int32, device=dev)
+        wsb = L.tomo_mc3_sort_workspace_bytes(cap_v)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.check(L.tomo_mc3_vertices(f.Nz, f.Ny, f.Nx, f.xorg, _p(m._vox_key), cap, _p(tot), _p(m._vox_loc), _p(m._vox_flags),
+                                       _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), _p(m._slice_tab), int(z_offset), 1, _p(cum_t), ncum,
+                                       _p(adj_t), nadj, mmy, mmx, _p(m._vrec), _p(keys), _p(idx), st), "tomo_mc3_vertices")
+        _lib.check(L.tomo_mc3_sort_rank(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, _p(m._slice_tab), _p(tot), _p(m._uniq), _p(m.table),
+                                        _p(ws), wsb, st), "tomo_mc3_sort_rank")
+
+    host = None
+    faces = None
+    if hint:
+        # everything is enqueued into buffers of hint + 25 % before any count is known; ONE download at the end
+        cap, cap_v, cap_f = (int(h * 1.25) + 4096 for h in hint)
+        if cap < LIST_LIMIT and cap < 2 ** 29 and cap_v < MESH_LIMIT and cap_f < MESH_LIMIT:
+            list_and_eval(cap)
+            eval_scan(cap, cap_v, cap_f)
+            vertices_sort(cap, cap_v)
+            m._cap_f = cap_f
+            if with_faces:
+                faces = m.faces()
+            host = _download_tot(tot)
+            if host[3]:
+                COUNTERS["mc3_hint_miss"] = COUNTERS.get("mc3_hint_miss", 0) + 1
+                host = faces = None                              # something did not fit: redo with exact sizes
+            else:
+                COUNTERS["mc3_hint_hit"] = COUNTERS.get("mc3_hint_hit", 0) + 1
+    if host is None:
+        list_and_eval(1 << 16)                                   # a token buffer: tot[0] comes out exact, nothing is written past it
+        na = _download_tot(tot)[0]
+        if na == 0:
+            return None
+        if na >= LIST_LIMIT or na >= 2 ** 29:
+            raise _lib.TomoError("surface too large for 32-bit indices")
+        list_and_eval(na)
+        eval_scan(na, 2 ** 31 - 2, 2 ** 31 - 2)
+        host = _download_tot(tot)
+        nv, nf = host[1], host[2]
+        if nv == 0:
+            _MC3_HINT[hint_key] = (na, 1, 1)
+            return None
+        if nv >= MESH_LIMIT or nf >= MESH_LIMIT:
+            raise _lib.TomoError("mesh too large for 32-bit indices")
+        vertices_sort(na, nv)
+        m._cap_f = max(nf, 1)
+        if with_faces:
+            faces = m.faces()
+        host = _download_tot(tot)
+    m.na, m.nv, m.nf = host[0], host[1], host[2]
+    if m.na == 0 or m.nv == 0:
+        return None
+    if m.na >= LIST_LIMIT:
+        raise _lib.TomoError("surface too large for 32-bit indices")
+    if m.nv >= MESH_LIMIT or m.nf >= MESH_LIMIT:
+        raise _lib.TomoError("mesh too large for 32-bit indices")
+    _MC3_HINT[hint_key] = (m.na, m.nv, m.nf)
+    m.uniq = m._uniq[:m.nv]
+    if host[4]:
+        # duplicate rows or a rounding coincidence: the general sort decides (np.unique semantics), the triangles follow
+        COUNTERS["mc3_general_unique"] = COUNTERS.get("mc3_general_unique", 0) + 1
+        rows = m._vrec[:m.nv, :3].contiguous()
+        uniq, rank = unique_rows(rows)
+        ids = m._vrec[:m.nv, 3].contiguous().view(torch.int32).to(torch.int64)
+        m.table[ids] = rank
+        m.uniq = uniq
+        if with_faces:
+            faces = m.faces(again=True)
+            host = _download_tot(tot)
+    else:
+        COUNTERS["mc3_exact"] = COUNTERS.get("mc3_exact", 0) + 1
+    if with_faces:
+        if host[6]:
+            raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % host[6])
+        faces = faces[:m.nf]
+        if host[5]:                                              # triangles with fewer than three distinct vertices are dropped, order kept
+            COUNTERS["mc3_degenerate"] = COUNTERS.get("mc3_degenerate", 0) + 1
+            keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+            faces = faces[keep]
+        m.faces_final = faces
+    return m
 
 
 def mesh_volume_area(verts: torch.Tensor, faces: torch.Tensor):
