@@ -247,8 +247,7 @@ def run(args, world):
         depths = np.full(gz, 1.0)
 
         def step():
-            vol = pipeline.pack(mask)
-            vol = pipeline.close_ends(vol, inplace=True)       # the packed copy is this pass's own
+            vol = pipeline.pack_closed(mask)                   # np.stack + _close_volume_ends, one pass over the mask
             vol = pipeline.smooth(vol, 3, True)
             return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
         parallelism = "single"

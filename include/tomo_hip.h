@@ -71,6 +71,11 @@ int tomo_popcount(const uint64_t *bits, int nz, int ny, int nx, unsigned long lo
 int tomo_fill_holes_slice(uint64_t *bits, int nz, int ny, int nx, int z, uint64_t *scratch, void *stream);
 /* The same for slices 0 and nz - 1 in one launch (the two floods are independent); same scratch. */
 int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream);
+/* np.stack + _close_volume_ends in one pass over the mask (voxel_processor.py:46, :56-77): the end slices are packed and
+ * filled first, then ONE streaming kernel packs every other slice and applies the recurrence, which is the local stencil
+ * c'[z] = c[z] | (c[z-1] & c[z+1]).  Needs nz >= 3, nx % 16 == 0 and a 16-byte aligned mask (TOMO_E_ARG otherwise: use
+ * tomo_pack_bits + tomo_fill_holes_ends + tomo_close_ends_scan).  scratch: ny * wx + 8 words. */
+int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream);
 /* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
  * workspace: tomo_close_ends_workspace_words() uint64 words. */
 int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);

@@ -154,6 +154,27 @@ def test_fill_holes_spiral(dev):
     assert np.array_equal(got[0], img) and np.array_equal(got[2], img)
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 16), (4, 9, 48), (33, 7, 64), (34, 6, 1040), (35, 3, 2064), (66, 11, 80), (70, 40, 128),
+                                   (2, 8, 32), (1, 8, 32), (5, 6, 20), (40, 12, 1024)])
+def test_pack_closed_one_pass_vs_oracle(dev, shape, monkeypatch):
+    """pipeline.pack_closed (end slices packed + filled, then the fused pack + three-tap stencil kernel) == the oracle's
+    _close_volume_ends recurrence == the separate pack / fill / carry-chain kernels, incl. runs that end at the last slice,
+    rows wider than one 1024-voxel group, and the layouts that take the fallback (nz < 3, nx % 16 != 0)."""
+    rng = np.random.default_rng(sum(shape))
+    for density in (0.3, 0.7):
+        v = rng.random(shape) < density
+        if shape[0] > 4:
+            v[1] = v[0] & v[2]                                  # single-voxel gaps along z: what the recurrence closes
+            v[shape[0] // 2] = False
+        mask = torch.from_numpy(v.view(np.uint8)).to(dev)
+        got = to_np(pipeline.pack_closed(mask))
+        assert np.array_equal(got, O.close_ends(v)), density
+        with monkeypatch.context() as m:
+            m.setattr(pipeline, "PACK_CLOSE_FUSED", False)
+            assert np.array_equal(to_np(pipeline.pack_closed(mask)), got)
+        assert np.array_equal(to_np(pipeline.pack(mask)), v)    # the mask itself is untouched
+
+
 def _fill_cases(ny, nx, rng):
     yy, xx = np.mgrid[0:ny, 0:nx]
     r2 = ((xx - (nx - 1) / 2) / (0.42 * nx)) ** 2 + ((yy - (ny - 1) / 2) / (0.40 * ny)) ** 2

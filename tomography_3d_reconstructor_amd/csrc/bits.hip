@@ -118,6 +118,69 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
     return tomo_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// pack + the z recurrence of _close_volume_ends in ONE pass over the mask (voxel_processor.py:46, :72-75).
+// The recurrence c'[z] = c[z] | (c'[z-1] & c[z+1]), z = 1 .. nz-2 (in place, ascending: c'[z-1] already updated, c[z+1] not
+// yet) is a LOCAL three-tap stencil: where c[z] = 0 the updated c'[z-1] = c[z-1] | (c'[z-2] & c[z]) is just c[z-1], and
+// where c[z] = 1 the result is 1 anyway -- so c'[z] = c[z] | (c[z-1] & c[z+1]) with c[0], c[nz-1] the FILLED end slices
+// (checked against the recurrence on random volumes, tests/test_oracle_golden.py).  Hence: pack and fill the two end slices
+// first (they are 2 of nz), then one streaming kernel packs every other slice and applies the stencil on the fly -- a wave
+// marches a run of PC_ZR slices of its (row, 1024-voxel group) with a three-word window, so the mask is read (PC_ZR + 2) /
+// PC_ZR times and the separate close-ends passes over the bit volume (4 launches, 66 us at 1024^3) disappear.
+#define PC_ZR 32
+__global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
+                                                         int nx, int wx, int groups, int runs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t per_run = (int64_t)ny * groups;
+    if (wid >= per_run * runs) return;
+    const int r = (int)(wid / per_run);
+    const int64_t rem = wid - (int64_t)r * per_run;
+    const int y = (int)(rem / groups), g = (int)(rem - (int64_t)y * groups);
+    const int x = g * 1024 + lane * 16, word = g * 16 + (lane >> 2);
+    const bool inx = x < nx, inw = word < wx;
+    const int z0 = 1 + r * PC_ZR, z1 = (z0 + PC_ZR < nz - 1) ? z0 + PC_ZR : nz - 1;          // outputs z0 .. z1-1
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int64_t slice_bytes = (int64_t)ny * nx, slice_words = (int64_t)ny * wx;
+    const uint8_t *mp = mask + (int64_t)y * nx + x;
+    u64 *bp = bits + (int64_t)y * wx + word;
+    // the 64-bit word of slice z for this lane's group of four lanes: an end slice comes from `bits` (packed and filled
+    // before this kernel), any other one from the mask
+    auto from_raw = [&](u4 t) -> u64 {
+        const u32 piece = nonzero_nibble(t.x) | (nonzero_nibble(t.y) << 4) | (nonzero_nibble(t.z) << 8) | (nonzero_nibble(t.w) << 12);
+        u64 w = (u64)piece << (16 * (lane & 3));
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        return w;
+    };
+    auto raw_of = [&](int z) -> u4 {
+        u4 t = {0u, 0u, 0u, 0u};
+        if (z > 0 && z < nz - 1 && inx) t = __builtin_nontemporal_load((const u4 *)(mp + (int64_t)z * slice_bytes));
+        return t;
+    };
+    auto word_of = [&](int z, u4 t) -> u64 {
+        if (z == 0 || z == nz - 1) return inw ? bp[(int64_t)z * slice_words] : 0ull;
+        return from_raw(t);
+    };
+    u64 prev = word_of(z0 - 1, raw_of(z0 - 1));
+    u64 cur = word_of(z0, raw_of(z0));
+    for (int z = z0; z < z1; z += 4) {
+        u4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) t[j] = z + j < z1 ? raw_of(z + 1 + j) : (u4){0u, 0u, 0u, 0u};   // four slices in flight
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (z + j >= z1) break;
+            const u64 next = word_of(z + 1 + j, t[j]);
+            const u64 out = cur | (prev & next);
+            if ((lane & 3) == 0 && inw) bp[(int64_t)(z + j) * slice_words] = out;
+            prev = cur;
+            cur = next;
+        }
+    }
+}
+
 // unpack: one thread per 8 voxels (one byte of the word) -> 8 output bytes.
 __global__ __launch_bounds__(256) void unpack_kernel(const u64 *__restrict__ bits, uint8_t *__restrict__ mask,
                                                      int64_t rows, int nx, int wx)
@@ -402,9 +465,24 @@ __global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const Fill
     u64 *Gd = p.comp + (size_t)sl * 3 * nb * wx, *Gu = Gd + (size_t)nb * wx, *P = Gu + (size_t)nb * wx;
     const int y0 = b * p.RB, rows = (p.ny - y0 < p.RB) ? p.ny - y0 : p.RB;
     const u64 tailmask = (p.nx & 63) ? ((1ull << (p.nx & 63)) - 1ull) : ~0ull;
+    // np.any(slice) guard of the reference (voxel_processor.py:60,66): an empty slice stays as it is.  Every workgroup finds
+    // that out for itself -- the slice is 128 KiB - 512 KiB in L2, sixteen bytes per lane and round -- so an empty end
+    // slice (the synthetic ellipsoid's) costs one short kernel and no grid barrier at all.
     if (tid == 0) s_any = 0;
     __syncthreads();
-    int any = 0;
+    {
+        const int64_t nw = (int64_t)p.ny * wx;
+        int any = 0;
+        if ((nw & 1) == 0 && (((uintptr_t)slice) & 15) == 0) {
+            const ulonglong2 *q = (const ulonglong2 *)slice;
+            for (int64_t i = tid; i < nw / 2; i += FB_THREADS) { const ulonglong2 v = q[i]; any |= (v.x | v.y) != 0; }
+        } else {
+            for (int64_t i = tid; i < nw; i += FB_THREADS) any |= slice[i] != 0;
+        }
+        if (any) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) return;                                             // the same answer in every workgroup of this slice
     for (int i = tid; i < rows * wx; i += FB_THREADS) {
         const int r = i / wx, w = i - r * wx, y = y0 + r;
         const u64 v = slice[(int64_t)y * wx + w];
@@ -416,11 +494,8 @@ __global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const Fill
         if (w == (p.nx - 1) / 64) seed |= freem & (1ull << ((p.nx - 1) & 63));
         F[i] = freem;
         R[i] = seed;
-        any |= v != 0;
     }
-    if (any) s_any = 1;
     __syncthreads();
-    if (tid == 0 && s_any) atomicOr((unsigned long long *)&ctrl[1], 1ull);
     fb_converge(R, F, rows, wx, &s_chg);
     for (int w = tid; w < wx; w += FB_THREADS) {
         u64 pr = ~0ull;
@@ -431,8 +506,6 @@ __global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const Fill
     }
     u64 k = 0;
     if (!fb_barrier(&ctrl[0], (u64)nb * ++k)) { if (tid == 0) ctrl[2] = 1; return; }
-    // np.any(slice) guard of the reference (voxel_processor.py:60,66): an empty slice stays as it is
-    if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int64_t max_rounds = (int64_t)p.ny * wx * 64 + 2;
     for (int64_t g = 0; g < max_rounds; g++) {
         if (tid == 0) s_chg = 0;
@@ -551,6 +624,31 @@ TOMO_API int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64
     if (wx > FH_THREADS) return TOMO_E_SIZE;
     u64 *first = (u64 *)bits, *last = nz > 1 ? (u64 *)bits + (int64_t)(nz - 1) * ny * wx : nullptr;
     return fill_holes_launch(first, last, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream);
+}
+
+// np.stack + _close_volume_ends (voxel_processor.py:46, :56-77) from the uint8 mask stack to the closed bit volume:
+// pack the two end slices, fill their holes, then the fused pack + stencil pass.  scratch: ny * wx + 8 words (the fill's).
+// Requires what pack16_kernel requires (nx % 16 == 0, 16-byte aligned mask) and nz >= 3; returns TOMO_E_ARG otherwise
+// (the caller then uses tomo_pack_bits + tomo_fill_holes_ends + tomo_close_ends_scan).
+TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream)
+{
+    if (!mask || !bits || !scratch || nz < 3 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    if (nx % 16 != 0 || (((uintptr_t)mask) & 15) != 0) return TOMO_E_ARG;
+    const int wx = (int)tomo_words_per_row(nx);
+    if (wx > FH_THREADS) return TOMO_E_SIZE;
+    const int groups = (wx + 15) / 16;
+    int rc = tomo_pack_bits(mask, bits, 1, ny, nx, stream);
+    if (rc) return rc;
+    rc = tomo_pack_bits(mask + (int64_t)(nz - 1) * ny * nx, bits + (int64_t)(nz - 1) * ny * wx, 1, ny, nx, stream);
+    if (rc) return rc;
+    rc = tomo_fill_holes_ends(bits, nz, ny, nx, scratch, stream);
+    if (rc) return rc;
+    const int runs = (nz - 2 + PC_ZR - 1) / PC_ZR;
+    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
+                       groups, runs);
+    return tomo_status();
 }
 
 // ------------------------------------------------------------------------------------------

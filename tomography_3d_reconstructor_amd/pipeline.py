@@ -24,6 +24,7 @@ NA_HINTS = os.environ.get("TOMO_NA_HINTS", "1") not in ("", "0")   # marching_cu
 _NA_HINT = {}
 LIST_LIMIT = 2 ** 31        # active-voxel list entries / vertices / triangles one pass can index (int32 offsets in mc.hip, mesh.hip);
 MESH_LIMIT = 2 ** 31        # beyond them marching_cubes raises TomoError (the drop-in class then returns None, as the reference would)
+PACK_CLOSE_FUSED = os.environ.get("TOMO_PACK_CLOSE", "1") not in ("", "0")   # pack_closed: one pass over the mask (A/B switch)
 FIELD_FROM_BITS = True      # False: materialise the extended bit volume first (tomo_extend_bits + tomo_field_fill)
 # extract_surface: do not materialise the parts of the float field that marching cubes cannot read (same mesh, ~0.4 ms less
 # per 1024^3 pass).  Off by default: the reference's path, and bench.py's roofline, speak of a dense per-voxel field.
@@ -143,6 +144,28 @@ def bounding_box(vol: BitVolume):
     _lib.check(_lib.lib().tomo_bbox(_p(vol.bits), nz, ny, nx, _p(box), _stream()), "tomo_bbox")
     b = [int(x) for x in box.cpu()]
     return None if b[1] < 0 else tuple(b)
+
+
+def pack_closed(mask: torch.Tensor) -> BitVolume:
+    """np.stack + _close_volume_ends (voxel_processor.py:46, :56-77) from a device uint8 / bool (nz, ny, nx) mask stack in ONE
+    pass over the mask where the layout allows it (nz >= 3, nx % 16 == 0): pack + fill the end slices, then the fused
+    pack + stencil kernel; otherwise pack, then close_ends in place."""
+    if mask.dim() != 3:
+        raise ValueError("mask must be (nz, ny, nx)")
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    if mask.dtype != torch.uint8:
+        raise TypeError("mask must be bool or uint8")
+    mask = mask.contiguous()
+    nz, ny, nx = mask.shape
+    if nz < 3 or nx % 16 != 0 or mask.data_ptr() % 16 != 0 or not PACK_CLOSE_FUSED:
+        return close_ends(pack(mask), inplace=True)
+    L = _lib.lib()
+    wx = L.tomo_words_per_row(nx)
+    bits = torch.empty((nz, ny, wx), dtype=torch.int64, device=mask.device)
+    scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=mask.device)
+    _lib.check(L.tomo_pack_close_ends(_p(mask), _p(bits), nz, ny, nx, _p(scratch), _stream()), "tomo_pack_close_ends")
+    return BitVolume(bits, (nz, ny, nx))
 
 
 def close_ends(vol: BitVolume, inplace: bool = False) -> BitVolume:

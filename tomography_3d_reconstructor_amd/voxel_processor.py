@@ -127,7 +127,7 @@ class VoxelProcessor:
             elif base is not None:
                 vol = pipeline.close_ends(to_device_volume(base), inplace=True)       # a fresh upload: ours to overwrite
             else:
-                vol = pipeline.close_ends(pipeline.pack(_stage_masks(mask_images)), inplace=True)
+                vol = pipeline.pack_closed(_stage_masks(mask_images))
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = to_host_volume(vol)
         else:

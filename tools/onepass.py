@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 mask = pipeline.ellipsoid_mask(n, n, n, dev).view(torch.uint8)
 depths = np.full(n, 1.0)
 for _ in range(4):
-    vol = pipeline.smooth(pipeline.close_ends(pipeline.pack(mask), inplace=True), 3, True)
+    vol = pipeline.smooth(pipeline.pack_closed(mask), 3, True)
     res = pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
 torch.cuda.synchronize()
 print(res[0].shape, res[1].shape)
