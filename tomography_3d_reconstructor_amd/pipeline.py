@@ -9,6 +9,7 @@ Reference lines each function replaces are given in its docstring.
 """
 import math
 import os
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -614,7 +615,7 @@ _PINNED_TOT = {}
 
 def _download_tot(tot):
     """The 8 counters of a chain in ONE transfer into page-locked memory (no pageable bounce buffer, no extra blit)."""
-    key = str(tot.device)
+    key = (str(tot.device), threading.get_ident())         # rank threads of a slab job share the process: one buffer each
     host = _PINNED_TOT.get(key)
     if host is None:
         host = _PINNED_TOT[key] = torch.empty(8, dtype=torch.int64, pin_memory=True)
@@ -644,6 +645,21 @@ class Mc3Surface:
         _lib.check(L.tomo_mc3_faces(f.Nz, f.Ny, f.Nx, f.xorg, _p(self._vox_key), self._cap, _p(self._tot), _p(self._seg_act),
                                     _p(self._seg_aoff), _p(self._vox_loc), _p(self._vox_til), _p(self._vox_used), _p(self._blk3), _p(tab), _p(faces),
                                     self._cap_f, st), "tomo_mc3_faces")
+        return faces
+
+    def faces_checked(self, table=None, again=False, faces=None):
+        """faces(table) + the download of the counters: raises on an internal inconsistency, drops the triangles with fewer
+        than three distinct vertices (order kept, surface_extractor.py:122-125) -> (F', 3) int64."""
+        if faces is None:
+            faces = self.faces(table, again)
+        host = _download_tot(self._tot)
+        if host[6]:
+            raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % host[6])
+        faces = faces[:host[2]]
+        if host[5]:
+            COUNTERS["mc3_degenerate"] = COUNTERS.get("mc3_degenerate", 0) + 1
+            keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+            faces = faces[keep]
         return faces
 
 

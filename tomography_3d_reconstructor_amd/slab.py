@@ -308,6 +308,13 @@ class HipEngine:
     def remap_faces(self, faces32, gid32):
         return pipeline.remap_faces(faces32, gid32)
 
+    def mc3_vertices(self, f, z_offset, depths, mm_y, mm_x):
+        """The production chain (pipeline.mc3_vertices): finalised, sorted, duplicate-free vertex rows of this slab plus
+        the table vertex id -> row index; the triangles are written later, through a table of GLOBAL indices."""
+        if not pipeline.MC3:
+            return NotImplemented
+        return pipeline.mc3_vertices(f, depths, mm_y, mm_x, True, z_offset=z_offset, with_faces=False)
+
     # reductions of the consumers (volume_calculator.py:23-35, 59-94) on the resident bit volume
     def slice_counts(self, vol):
         return pipeline.slice_counts(vol)
@@ -427,8 +434,13 @@ class SlabJob:
                 e.field_set_slice(f, fb, top)
         f = e.field_slices(f, fa, fb + (0 if last else 1))
         Za = 0 if first else self.z0 + 1            # global padded index of the first owned slice
-        mesh = e.marching_cubes(f, Za)
         dev = mask.device
+        if hasattr(e, "mc3_vertices"):
+            m = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x)
+            if m is not NotImplemented:
+                self.mesh = self._global_numbering_mc3(m, slice_depths, dev)
+                return self.mesh
+        mesh = e.marching_cubes(f, Za)
         vkey = ny = None
         if mesh is None:
             vpos = torch.zeros((0, 3), dtype=torch.float32, device=dev)
@@ -442,22 +454,18 @@ class SlabJob:
         return self.mesh
 
     # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
-    def _global_numbering(self, vpos, faces32, slice_depths, dev, vkey=None, ny=None):
+    def _number_rows(self, uniq, slice_depths, dev):
+        """uniq: this rank's sorted, duplicate-free vertex rows (nu, 3).  -> (the rows this rank keeps, gid int64 (nu,):
+        the GLOBAL index of every one of the nu rows).  Sets self.vertex_offset / self.n_vertices_global."""
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
-        nv = vpos.shape[0]
-        fast = vkey is not None and ny is not None and hasattr(e, "unique_mc")     # rows in marching-cubes order, with keys
-        # 1. ALL vertices of this rank: sorted unique rows + the index of every provisional vertex in them
-        if nv:
-            uniq, rank = e.unique_mc(vpos, vkey, ny, getattr(self, "_mesh_nz", 0)) if fast else e.unique(vpos.contiguous())
-        else:
-            uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
+        nu0 = nu = uniq.shape[0]
         if self.world == 1:
-            self.vertex_offset, self.n_vertices_global = 0, uniq.shape[0]
-            return uniq, self._faces(faces32, rank.to(torch.int64))
-        # 2. the rows on the plane shared with rank+1 (mapped z of padded plane z1 + 1, through the same finalisation
-        #    arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1
-        nu, n_top = uniq.shape[0], 0
+            self.vertex_offset, self.n_vertices_global = 0, nu
+            return uniq, torch.arange(nu, dtype=torch.int64, device=dev)
+        # the rows on the plane shared with rank+1 (mapped z of padded plane z1 + 1, through the same finalisation
+        # arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1
+        n_top = 0
         if not last and nu:
             zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
             if getattr(self, "_zb_key", None) != zkey:             # depends on the depth table only: once per table
@@ -465,11 +473,12 @@ class SlabJob:
                 self._zb, self._zb_key = float(e.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
             n_top = int((uniq[:, 0] == self._zb).sum().item())
         k = nu - n_top                                             # rows this rank keeps
-        # 3. they go up (count first); what arrives from below are copies of rows this rank has itself: look them up
+        # they go up (count first); what arrives from below are copies of rows this rank has itself: look them up
         cnt_prev, _ = c.exchange(None, torch.tensor([n_top], dtype=torch.int64, device=dev), torch.int64)
         n_from_prev = int(cnt_prev.item()) if cnt_prev is not None else 0
         from_prev, _ = c.exchange(None, uniq[k:].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
         idx_prev = torch.zeros(0, dtype=torch.int32, device=dev)
+        remap = None                                               # old row index -> row index after a merge
         if from_prev is not None and from_prev.shape[0]:
             prev_rows = from_prev.reshape(-1, 3).contiguous()
             missing = 1
@@ -478,23 +487,51 @@ class SlabJob:
             if missing:
                 # a row from below that is new here (or an engine without lookup): merge the two sorted lists properly
                 merged, r2 = e.unique(torch.cat([uniq, prev_rows], 0).contiguous())
-                rank = r2[:nu][rank.to(torch.int64)]
+                remap = r2[:nu].to(torch.int64)
                 idx_prev = r2[nu:]
                 uniq, nu = merged, merged.shape[0]
                 k = nu - n_top
-        # 4. their indices go back down; the kept counts give every rank its offset
+        # their indices go back down; the kept counts give every rank its offset
         _, ids_next = c.exchange(idx_prev.contiguous(), None, torch.int32, recv_shape_next=(n_top,))
         counts = c.all_gather(torch.tensor([k], dtype=torch.int64, device=dev))
         counts = [int(x.item()) for x in counts]
         offs = np.concatenate([[0], np.cumsum(counts)])
         self.vertex_offset, self.n_vertices_global = int(offs[self.rank]), int(offs[-1])
-        # 5. global index of every provisional vertex: own rows by rank, shared-plane rows through the upper rank's ids
-        r64 = rank.to(torch.int64)
-        gid = r64 + int(offs[self.rank])
+        # own rows by position, shared-plane rows through the upper rank's ids
+        gid = torch.arange(nu, dtype=torch.int64, device=dev) + int(offs[self.rank])
         if n_top:
-            up = ids_next.to(torch.int64)[(r64 - k).clamp(min=0)] + int(offs[self.rank + 1])
-            gid = torch.where(r64 >= k, up, gid)
-        return uniq[:k], self._faces(faces32, gid)
+            gid[k:] = ids_next.to(torch.int64) + int(offs[self.rank + 1])
+        if remap is not None:
+            gid = gid[remap]
+        assert gid.shape[0] == nu0
+        return uniq[:k], gid
+
+    def _global_numbering(self, vpos, faces32, slice_depths, dev, vkey=None, ny=None):
+        e = self.eng
+        nv = vpos.shape[0]
+        fast = vkey is not None and ny is not None and hasattr(e, "unique_mc")     # rows in marching-cubes order, with keys
+        # ALL vertices of this rank: sorted unique rows + the index of every provisional vertex in them
+        if nv:
+            uniq, rank = e.unique_mc(vpos, vkey, ny, getattr(self, "_mesh_nz", 0)) if fast else e.unique(vpos.contiguous())
+        else:
+            uniq, rank = vpos, torch.zeros(0, dtype=torch.int32, device=dev)
+        kept, gid_rows = self._number_rows(uniq, slice_depths, dev)
+        return kept, self._faces(faces32, gid_rows[rank.to(torch.int64)])
+
+    def _global_numbering_mc3(self, m, slice_depths, dev):
+        """The same for the mc3 chain: m.uniq are this rank's sorted unique rows, m.table maps a vertex id to its row; the
+        triangles are written once, straight through the table of GLOBAL indices."""
+        if m is None:                                              # no surface in this slab: still take part in the exchanges
+            empty = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+            kept, _ = self._number_rows(empty, slice_depths, dev)
+            return kept, torch.zeros((0, 3), dtype=torch.int64, device=dev)
+        nu = m.uniq.shape[0]
+        kept, gid_rows = self._number_rows(m.uniq, slice_depths, dev)
+        if self.n_vertices_global >= 2 ** 31:
+            raise pipeline._lib.TomoError("more than 2^31 vertices: the triangle table holds 32-bit indices")
+        # entries of the table that belong to no vertex hold whatever was in memory: clamp before they index anything
+        table_g = gid_rows.to(torch.int32)[m.table.clamp_(0, max(nu - 1, 0))]
+        return kept, m.faces_checked(table_g, again=True)
 
     def _faces(self, faces32, gid):
         if faces32.shape[0] == 0:
