@@ -51,13 +51,13 @@ def find(d, sub):
 fk = "field_tile_kernel"
 fkb, wkb = find(fetch, fk), find(write, fk)
 field_us = [sum(v) / len(v) for k, v in acc.items() if fk in k][0]
-pmcj = {"kernel": fk, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+pmcj = {"kernel": fk, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras",
         "fetch_size_kb_raw": fkb, "write_size_kb": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024,
-        "correction": "reads x2 (gfx950 FETCH_SIZE counts half of the bytes of coalesced reads; calibrated on pack16_kernel's "
-                      "exact 1 GiB), writes exact", "kernel_us_in_trace": field_us}
+        "correction": "reads x2 (gfx950 FETCH_SIZE counts half of the bytes of coalesced reads; calibrated in round 1 on "
+                      "pack16_kernel's exact 1 GiB -- pack_close_kernel reads 34/32 of it), writes exact", "kernel_us_in_trace": field_us}
 json.dump(pmcj, open(os.path.join(out, "%s_field_pmc.json" % tag), "w"), indent=1)
 
-md = ["# Round profile `%s` -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`\n" % tag,
+md = ["# Round profile `%s` -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras`\n" % tag,
       "MI355X (gfx950), 1024^3 ellipsoid, 9 passes of the hot path (2 priming + 2 warm-up + 5 timed).  Full CSV: `%s_bench_kernel_stats.csv`.\n" % tag,
       "Bench line of the profiled run: `%s`\n" % last_json(os.path.join(out, "bench_trace.log")),
       "Bench line, un-profiled (`python bench.py`): `%s`\n" % last_json(os.path.join(out, "bench_plain.log")),
@@ -66,16 +66,20 @@ for n, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     md.append("| `%s` | %d | %.2f | %.3f | %.2f |" % (n[:70], len(v), sum(v) / len(v), sum(v) / PASSES / 1e3, 100 * sum(v) / tot))
 md.append("\n(`at::native::*` kernels are the synthetic-mask generation before the timed region.)\n")
 md.append("\n## PMC passes (separate runs of the same command: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`), per dispatch, KB\n")
-md.append("Calibration: `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
-          "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below.  WRITE_SIZE is exact.\n")
+md.append("Calibration (round 1): `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
+          "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below (`pack_close_kernel` reads 34/32 GiB: every run of 32 "
+          "slices re-reads its two neighbours).  WRITE_SIZE is exact.\n")
 md.append("| kernel | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM bytes = 2*FETCH + WRITE |\n|---|---|---|---|")
-for sub in ("pack16_kernel", "morph_wave_kernel<4, 6>", "morph_wave_kernel<4, 5>", fk, "mc_classify_bits_kernel", "mc_emit_kernel"):
+for sub in ("pack_close_kernel", "morph_wave32_kernel<4, 6", "morph_wave32_kernel<4, 5", fk, "mc_classify_bits_kernel", "mc3_list_kernel", "mc3_eval_kernel",
+            "mc3_vertices_kernel", "rocprim", "uq3_rank_kernel", "mc3_faces_kernel"):
     a, b = find(fetch, sub), find(write, sub)
     if a is not None and b is not None:
         md.append("| `%s` | %.0f | %.0f | %.3e |" % (sub, a, b, (2 * a + b) * 1024))
 alg = 5.0 * 1026 ** 3
 md.append("\nField (\"SDF\") kernel `%s`: avg %.1f us per launch in this trace -> algorithmic 5 B x 1026^3 = %.3e B / launch = %.0f GB/s "
-          "= %.1f %% of the 8 TB/s HBM3E peak; measured HBM traffic %.3e B per launch.\n"
-          % (fk, field_us, alg, alg / field_us / 1e3, alg / field_us / 1e3 / 80.0, pmcj["hbm_bytes_per_launch"]))
+          "= %.1f %% of the 8 TB/s HBM3E peak (SURVEY 8(d)'s accounting: 1 B mask + 4 B field per padded voxel); measured HBM traffic %.3e B per launch "
+          "= %.0f GB/s = %.1f %% of peak by the bytes the kernel moves (it reads the bit-packed volume; the 1 B/voxel mask is read by pack_close_kernel).\n"
+          % (fk, field_us, alg, alg / field_us / 1e3, alg / field_us / 1e3 / 80.0, pmcj["hbm_bytes_per_launch"],
+             pmcj["hbm_bytes_per_launch"] / field_us / 1e3, pmcj["hbm_bytes_per_launch"] / field_us / 1e3 / 80.0))
 open(os.path.join(out, "%s_bench_profile.md" % tag), "w").write("\n".join(md))
 print("\n".join(md[-3:]))
