@@ -44,6 +44,7 @@ typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));      // one 12-byte store per vertex / triangle
 typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef u32 u32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ static inline u64 make_key(int64_t row, int X, int slot)
 {
@@ -1164,7 +1165,8 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_faces_kernel(const McGrid g, cons
         const u64 k##n = need##n ? (okey) : key;                                                                                   \
         const u32 cc##n = ((u32)(k##n >> 2) & ((1u << KEY_XBITS) - 1u)) + (u32)g.xorg + SEG_SHIFT;                                 \
         const u64 seg##n = (k##n >> (KEY_XBITS + 2)) * (u64)g.segs_per_row + (cc##n >> 8);                                         \
-        const u32 a0_##n = seg_aoff[seg##n], a1_##n = seg_aoff[seg##n + 1];                                                        \
+        const u32x2u aa##n = *(const u32x2u *)(seg_aoff + seg##n);      /* (offset, next offset): one 8-byte, 4-byte aligned load */  \
+        const u32 a0_##n = aa##n.x, a1_##n = aa##n.y;                                                                              \
         const Rec4 rec##n = load_rec(seg_act, (int64_t)seg##n);       /* garbage for an empty segment: masked below */
         MC3_OWNER(2, MC3_USED((1u << 2) | (1u << 11)), make_key(row + 1, X, 0))
         MC3_OWNER(3, MC3_USED((1u << 4) | (1u << 7)), make_key(row + rowY, X, 0))
