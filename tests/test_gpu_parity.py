@@ -826,6 +826,52 @@ def test_marching_cubes_size_hints(dev):
     assert pipeline.COUNTERS.get("na_hint_hit", 0) - c0.get("na_hint_hit", 0) >= 3
 
 
+def test_mc3_chain_size_hints(dev):
+    """The mc3 chain is enqueued into buffers sized from the counts of the last surface of the same geometry (+ 25 %) before
+    anything comes back from the device: same mesh as the oracle when the hint holds, when it is far too large, when it is
+    too small in the list / the vertices / the triangles (flagged on the device, nothing written past a buffer, the pass is
+    redone with exact sizes), without hints, and for an empty volume after a full one."""
+    rng = np.random.default_rng(6)
+    shape = (24, 60, 144)
+    small = np.zeros(shape, bool); small[10:14, 20:30, 30:60] = True
+    big = rng.random(shape) < 0.5                                   # noise: a far longer list, centre vertices, duplicate rows
+    mid = np.stack(O.ellipsoid_masks(*shape))
+    empty = np.zeros(shape, bool)
+    depths = np.linspace(0.2, 0.6, shape[0])
+    ref = {k: O.SurfaceExtractor().extract_manifold_surface(v, depths, 0.8, 1.1) for k, v in
+           (("small", small), ("big", big), ("mid", mid), ("empty", empty))}
+    vols = {"small": small, "big": big, "mid": mid, "empty": empty}
+    assert pipeline.MC3 and pipeline.NA_HINTS
+    pipeline._MC3_HINT.clear()
+    c0 = dict(pipeline.COUNTERS)
+    for k in ["small", "small", "big", "big", "mid", "small", "empty", "big", "empty", "mid"]:
+        got = pipeline.extract_surface(to_vol(vols[k], dev), depths, 0.8, 1.1)
+        if ref[k] is None:
+            assert got is None, k
+            continue
+        assert got[0].cpu().numpy().tobytes() == ref[k][0].tobytes() and np.array_equal(got[1].cpu().numpy(), ref[k][1]), k
+    assert pipeline.COUNTERS.get("mc3_hint_miss", 0) - c0.get("mc3_hint_miss", 0) >= 2
+    assert pipeline.COUNTERS.get("mc3_hint_hit", 0) - c0.get("mc3_hint_hit", 0) >= 3
+    # a hint that fits the list but not the vertices / not the triangles
+    for which in (1, 2):
+        pipeline.extract_surface(to_vol(mid, dev), depths, 0.8, 1.1)
+        key = next(iter(k for k in pipeline._MC3_HINT if k[0] == shape[0] + 2))
+        h = list(pipeline._MC3_HINT[key])
+        h[which] = 8
+        pipeline._MC3_HINT[key] = tuple(h)
+        miss = pipeline.COUNTERS.get("mc3_hint_miss", 0)
+        got = pipeline.extract_surface(to_vol(big, dev), depths, 0.8, 1.1)
+        assert pipeline.COUNTERS.get("mc3_hint_miss", 0) == miss + 1
+        assert got[0].cpu().numpy().tobytes() == ref["big"][0].tobytes() and np.array_equal(got[1].cpu().numpy(), ref["big"][1])
+    with_hints = pipeline.extract_surface(to_vol(big, dev), depths, 0.8, 1.1)
+    pipeline.NA_HINTS = False
+    try:
+        without = pipeline.extract_surface(to_vol(big, dev), depths, 0.8, 1.1)
+    finally:
+        pipeline.NA_HINTS = True
+    assert torch.equal(with_hints[0], without[0]) and torch.equal(with_hints[1], without[1])
+
+
 # ------------------------------------------------------------------ masks that touch the first / last slice
 @pytest.mark.parametrize("kind", ["first", "both", "noise_first"])
 def test_one_sort_unique_with_clamped_first_slice(dev, kind):
