@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0) with metric/value/unit..., plus
   roofline:      the field ("SDF") kernel: `achieved`/`frac` = algorithmic 5 B per padded voxel / measured kernel time
                  (HIP events on the launch stream, inside the timed region) vs the 8 TB/s HBM3E peak; `frac_traffic` =
                  the same with the bytes the kernel actually moves (rocprofv3 counters, separate passes; the kernel
-                 reads the bit-packed volume, not the 1 B/voxel mask -- that is read by pack16_kernel);
+                 reads the bit-packed volume, not the 1 B/voxel mask -- that is read by pack_close_kernel);
   pass_floor:    the whole pass against its own HBM floor (1 B mask in + 4 B field out per voxel);
   cold_pass_ms, host_to_host_ms: one pass without the size hints of earlier passes; the three drop-in class methods
                  host list in -> host arrays out (PCIe inclusive) -- reported beside `value`, never as `value`;
@@ -294,7 +294,7 @@ def run(args, world):
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": alg, "kernel_ms": round(fms, 4),
                     "note": "achieved/frac: SURVEY 8(d)'s 5 B per padded voxel (1 B mask + 4 B f32) / kernel time. The kernel itself "
-                            "reads the bit-packed volume (1/8 B per voxel); the 1 B/voxel mask is read by pack16_kernel. "
+                            "reads the bit-packed volume (1/8 B per voxel); the 1 B/voxel mask is read by pack_close_kernel. "
                             "frac_traffic prices the kernel by the bytes it moves."}
         pmc = next((p for p in (FIELD_PMC, FIELD_PMC_OLD) if os.path.exists(os.path.join(ROOT, p))), None)
         if not dist and pmc and (gz, ny, nx) == (1024, 1024, 1024) and not args.sparse_field:

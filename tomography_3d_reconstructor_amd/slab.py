@@ -2,11 +2,10 @@
 
 The reference is single-process; this is the scale-out of the SAME path: the volume is
 cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, all with the z-neighbours
-(RCCL send/recv over xGMI) plus one tiny all-gather:
+(RCCL send/recv over xGMI) plus one tiny all-gather (the vertex counts):
 
-  close ends   per-column carry chain c'[z] = c[z] | (c[z+1] & c'[z-1]): every rank reduces its slab to a
-               (G, P) pair of bit planes, the pairs are all-gathered (2 x ny*nx bits per rank) and folded into
-               each rank's carry-in; the first slice of rank r+1 is the one extra input slice.
+  close ends   c'[z] = c[z] | (c[z+1] & c'[z-1]) is the local stencil c[z] | (c[z-1] & c[z+1]): one ORIGINAL slice
+               from either neighbour (one two-way exchange of one bit-packed slice), no carry from further away.
   smoothing    8 passes of a radius-1 stencil + 2 slices for the Gaussian: one exchange of 10 bit-packed halo
                slices per side, after which every pass runs locally (the contaminated rim shrinks into the halo).
   field        computed locally on the halo-extended slab; the owned field slices are exact.
@@ -360,26 +359,21 @@ class SlabJob:
         if self.world == 1:
             e.close_scan(vol)
             return e.bits(vol)
-        # the original first slice of the next rank is the extra input of the chain
-        _, nxt = c.exchange(bits[:1], None, torch.int64)
-        if buf is not None:     # the slice before (placeholder for the carry) and after (next rank's first) go in place
+        # c'[z] = c[z] | (c'[z-1] & c[z+1]) is the LOCAL stencil c[z] | (c[z-1] & c[z+1]) (where c[z] = 0 the updated
+        # neighbour c'[z-1] is just c[z-1]: DESIGN.md 4.2), so a slab needs exactly one ORIGINAL slice from either
+        # neighbour -- its last slice from below, its first from above -- and no carry from further away: one two-way
+        # exchange, then the recurrence kernel on [slice below | slab | slice above] with those two as fixed ends.
+        below, above = c.exchange(bits[:1], bits[nzl - 1:], torch.int64)
+        if buf is not None:     # the two neighbour slices go in place, next to the slab
             lo_i, hi_i = room - (0 if first else 1), room + nzl + (0 if last else 1)
             if not last:
-                buf[room + nzl].copy_(nxt[0])
+                buf[room + nzl].copy_(above[0])
             if not first:
-                buf[room - 1].zero_()
+                buf[room - 1].copy_(below[0])
             ext = e.from_bits(buf[lo_i:hi_i], (hi_i - lo_i, self.ny, self.nx))
         else:
-            parts = ([] if first else [torch.zeros_like(bits[:1])]) + [bits] + ([] if last else [nxt])
+            parts = ([] if first else [below]) + [bits] + ([] if last else [above])
             ext = e.from_bits(torch.cat(parts, 0), (nzl + len(parts) - 1, self.ny, self.nx))
-        G, P = e.close_gp(ext)
-        gathered = c.all_gather(torch.stack([G, P, bits[0]], 0))
-        carry = gathered[0][2]                                      # c'[0] = (filled) global slice 0
-        for q in range(self.rank):                                  # fold the lower ranks' (G, P)
-            carry = gathered[q][0] | (gathered[q][1] & carry)
-        xb = e.bits(ext)
-        if not first:
-            xb[0] = carry
         e.close_scan(ext)
         xb = e.bits(ext)
         return xb[(0 if first else 1):(0 if first else 1) + nzl]
@@ -494,7 +488,7 @@ class SlabJob:
         # their indices go back down; the kept counts give every rank its offset
         _, ids_next = c.exchange(idx_prev.contiguous(), None, torch.int32, recv_shape_next=(n_top,))
         counts = c.all_gather(torch.tensor([k], dtype=torch.int64, device=dev))
-        counts = [int(x.item()) for x in counts]
+        counts = [int(x) for x in torch.cat([t.reshape(1) for t in counts]).cpu()]        # one download, not one per rank
         offs = np.concatenate([[0], np.cumsum(counts)])
         self.vertex_offset, self.n_vertices_global = int(offs[self.rank]), int(offs[-1])
         # own rows by position, shared-plane rows through the upper rank's ids
