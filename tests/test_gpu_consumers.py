@@ -219,3 +219,43 @@ def test_repeated_calls_reuse_the_device_result(dev):
         empty = np.zeros((6, 8, 8), bool)
         assert se.extract_manifold_surface(empty, np.full(6, 1.0), 1.0, 1.0) is None
     _memo.clear()
+
+
+def test_mesh_measures_check_their_indices_like_numpy(dev):
+    """calculate_mesh_volume / calculate_surface_area index `vertices` with the caller's `faces` (surface_extractor.py:133-136,
+    144-146): NumPy wraps negative indices and raises IndexError beyond the list; the device kernel must never read there."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    f = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]], np.int64)
+    se, ose = SurfaceExtractor(), O.SurfaceExtractor()
+    assert np.isclose(se.calculate_mesh_volume(v, f), ose.calculate_mesh_volume(v, f), rtol=1e-6)
+    wrapped = f.copy(); wrapped[wrapped == 3] = -1                           # -1 is the last vertex, as in NumPy
+    assert np.isclose(se.calculate_mesh_volume(v, wrapped), ose.calculate_mesh_volume(v, f), rtol=1e-6)
+    assert np.isclose(float(se.calculate_surface_area(v, wrapped)), float(ose.calculate_surface_area(v, f)), rtol=1e-6)
+    for bad in (4, 10 ** 9, -5):
+        g = f.copy(); g[2, 1] = bad
+        with pytest.raises(IndexError):
+            se.calculate_mesh_volume(v, g)
+        with pytest.raises(IndexError):
+            se.calculate_surface_area(v, g)
+    assert se.calculate_mesh_volume(v, np.zeros((0, 3), np.int64)) == 0.0
+
+
+def test_fractional_threshold_rounds_up(dev, tmp_path):
+    """image_loader.py:108 compares integer grey levels with `>= threshold`: for a threshold of 199.5 the level 199 is out and
+    200 is in, on the host masks AND on the device copy the loader caches (pack_threshold truncated it in round 1)."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    grey = rng.integers(195, 205, (5, 16, 32), dtype=np.uint8)
+    for k, sec in enumerate(("Section_0", "Section_1", "Section_2")):
+        os.makedirs(tmp_path / sec)
+    for z in range(5):
+        Image.fromarray(grey[z], mode="L").save(tmp_path / "Section_1" / ("Mask_P_%d.png" % z))
+    ld = ImageLoader()
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert ld.load_mask_images(str(tmp_path), 199.5, [True, True, True])
+        masks = ld.get_mask_images()
+        assert np.array_equal(np.stack(masks), grey >= 199.5) and np.array_equal(np.stack(masks), grey >= 200)
+        vol = VoxelProcessor().create_voxel_data(masks, False, 0, 5, 0)           # served from the loader's device copy
+    assert np.array_equal(vol, grey >= 200)
+    dv = pipeline.pack_threshold(torch.from_numpy(grey).to(dev), 199.5)
+    assert np.array_equal(pipeline.unpack(dv).cpu().numpy(), grey >= 200)

@@ -127,7 +127,12 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
 // first (they are 2 of nz), then one streaming kernel packs every other slice and applies the stencil on the fly -- a wave
 // marches a run of PC_ZR slices of its (row, 1024-voxel group) with a three-word window, so the mask is read (PC_ZR + 2) /
 // PC_ZR times and the separate close-ends passes over the bit volume (4 launches, 66 us at 1024^3) disappear.
-#define PC_ZR 32
+#ifndef PC_ZR
+#define PC_ZR 32        // slices per wave run (the mask is read (PC_ZR + 2) / PC_ZR times)
+#endif
+#ifndef PC_U
+#define PC_U 4          // slices whose 16-byte loads are in flight together per lane
+#endif
 __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
                                                          int nx, int wx, int groups, int runs)
 {
@@ -165,12 +170,12 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
     };
     u64 prev = word_of(z0 - 1, raw_of(z0 - 1));
     u64 cur = word_of(z0, raw_of(z0));
-    for (int z = z0; z < z1; z += 4) {
-        u4 t[4];
+    for (int z = z0; z < z1; z += PC_U) {
+        u4 t[PC_U];
 #pragma unroll
-        for (int j = 0; j < 4; j++) t[j] = z + j < z1 ? raw_of(z + 1 + j) : (u4){0u, 0u, 0u, 0u};   // four slices in flight
+        for (int j = 0; j < PC_U; j++) t[j] = z + j < z1 ? raw_of(z + 1 + j) : (u4){0u, 0u, 0u, 0u};   // PC_U slices in flight
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PC_U; j++) {
             if (z + j >= z1) break;
             const u64 next = word_of(z + 1 + j, t[j]);
             const u64 out = cur | (prev & next);
