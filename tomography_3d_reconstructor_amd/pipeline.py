@@ -517,17 +517,18 @@ def unique_rows(vpos: torch.Tensor, vkey: torch.Tensor = None, ny: int = None, n
         return uniq[: int(host[0])], rank
 
 
-def lookup_rows(uniq: torch.Tensor, query: torch.Tensor):
-    """Index of every query row in the sorted unique row list -> (idx (Q,) int32, number of rows not found)."""
+def lookup_rows(uniq: torch.Tensor, query: torch.Tensor, sync: bool = True):
+    """Index of every query row in the sorted unique row list -> (idx (Q,) int32, number of rows not found -- an int, or
+    with sync=False the 1-element device tensor, so that the caller can fold the download into a later one)."""
     dev = uniq.device
     nq = query.shape[0]
     out = torch.empty(nq, dtype=torch.int32, device=dev)
-    if nq == 0:
-        return out, 0
     miss = torch.zeros(1, dtype=torch.int64, device=dev)
+    if nq == 0:
+        return out, (0 if sync else miss)
     _lib.check(_lib.lib().tomo_mesh_lookup(_p(uniq.contiguous()), uniq.shape[0], _p(query.contiguous()), nq, _p(out), _p(miss),
                                            _stream()), "tomo_mesh_lookup")
-    return out, int(miss.item())
+    return out, (int(miss.item()) if sync else miss)
 
 
 def remap_faces(faces32: torch.Tensor, gid32: torch.Tensor):

@@ -304,6 +304,10 @@ class HipEngine:
     def lookup(self, uniq, query):
         return pipeline.lookup_rows(uniq, query)
 
+    def lookup_async(self, uniq, query):
+        """lookup() without the host round trip: the miss count stays on the device (a 1-element int64 tensor)."""
+        return pipeline.lookup_rows(uniq, query, sync=False)
+
     def remap_faces(self, faces32, gid32):
         return pipeline.remap_faces(faces32, gid32)
 
@@ -458,37 +462,50 @@ class SlabJob:
             self.vertex_offset, self.n_vertices_global = 0, nu
             return uniq, torch.arange(nu, dtype=torch.int64, device=dev)
         # the rows on the plane shared with rank+1 (mapped z of padded plane z1 + 1, through the same finalisation
-        # arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1
-        n_top = 0
+        # arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1.  Their number is
+        # counted on the device, handed up as a device scalar, and ONE download brings this rank's and the lower rank's.
+        nt = torch.zeros(1, dtype=torch.int64, device=dev)
         if not last and nu:
             zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
             if getattr(self, "_zb_key", None) != zkey:             # depends on the depth table only: once per table
                 zt = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
                 self._zb, self._zb_key = float(e.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
-            n_top = int((uniq[:, 0] == self._zb).sum().item())
+            nt = (uniq[:, 0] == self._zb).sum().reshape(1).to(torch.int64)
+        cnt_prev, _ = c.exchange(None, nt, torch.int64)
+        pair = torch.cat([nt, cnt_prev.reshape(1) if cnt_prev is not None else torch.zeros_like(nt)]).cpu()
+        n_top, n_from_prev = int(pair[0]), int(pair[1])
         k = nu - n_top                                             # rows this rank keeps
-        # they go up (count first); what arrives from below are copies of rows this rank has itself: look them up
-        cnt_prev, _ = c.exchange(None, torch.tensor([n_top], dtype=torch.int64, device=dev), torch.int64)
-        n_from_prev = int(cnt_prev.item()) if cnt_prev is not None else 0
+        # they go up; what arrives from below are copies of rows this rank has itself: look them up
         from_prev, _ = c.exchange(None, uniq[k:].contiguous(), torch.float32, recv_shape_prev=(n_from_prev, 3))
         idx_prev = torch.zeros(0, dtype=torch.int32, device=dev)
         remap = None                                               # old row index -> row index after a merge
+        prev_rows = None
+        miss = torch.zeros(1, dtype=torch.int64, device=dev)
         if from_prev is not None and from_prev.shape[0]:
             prev_rows = from_prev.reshape(-1, 3).contiguous()
-            missing = 1
-            if hasattr(e, "lookup") and nu:
-                idx_prev, missing = e.lookup(uniq, prev_rows)
-            if missing:
-                # a row from below that is new here (or an engine without lookup): merge the two sorted lists properly
+            if hasattr(e, "lookup_async") and nu:
+                idx_prev, miss = e.lookup_async(uniq, prev_rows)
+            elif hasattr(e, "lookup") and nu:
+                idx_prev, m = e.lookup(uniq, prev_rows)
+                miss = torch.full((1,), int(m), dtype=torch.int64, device=dev)
+            else:
+                miss = torch.ones(1, dtype=torch.int64, device=dev)   # an engine without lookup: merge the two lists
+        # the kept counts give every rank its offset; the same all-gather tells every rank whether ANY rank found a row from
+        # below that is new to it -- that rank merges the two sorted lists properly, which changes its count, and the counts
+        # are gathered once more (rare with the HIP engine: the lower rank's shared-plane rows are this rank's own)
+        got = torch.stack(c.all_gather(torch.cat([torch.tensor([k], dtype=torch.int64, device=dev), miss]))).cpu()
+        counts, misses = [int(x) for x in got[:, 0]], [int(x) for x in got[:, 1]]
+        if any(misses):
+            if misses[self.rank]:
                 merged, r2 = e.unique(torch.cat([uniq, prev_rows], 0).contiguous())
                 remap = r2[:nu].to(torch.int64)
                 idx_prev = r2[nu:]
                 uniq, nu = merged, merged.shape[0]
                 k = nu - n_top
-        # their indices go back down; the kept counts give every rank its offset
+            got = torch.stack(c.all_gather(torch.tensor([k], dtype=torch.int64, device=dev))).cpu()
+            counts = [int(x) for x in got[:, 0]]
+        # the indices of the rows that came from below go back down
         _, ids_next = c.exchange(idx_prev.contiguous(), None, torch.int32, recv_shape_next=(n_top,))
-        counts = c.all_gather(torch.tensor([k], dtype=torch.int64, device=dev))
-        counts = [int(x) for x in torch.cat([t.reshape(1) for t in counts]).cpu()]        # one download, not one per rank
         offs = np.concatenate([[0], np.cumsum(counts)])
         self.vertex_offset, self.n_vertices_global = int(offs[self.rank]), int(offs[-1])
         # own rows by position, shared-plane rows through the upper rank's ids
