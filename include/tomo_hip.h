@@ -76,6 +76,11 @@ int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64_t *scrat
  * c'[z] = c[z] | (c[z-1] & c[z+1]).  Needs nz >= 3, nx % 16 == 0 and a 16-byte aligned mask (TOMO_E_ARG otherwise: use
  * tomo_pack_bits + tomo_fill_holes_ends + tomo_close_ends_scan).  scratch: ny * wx + 8 words. */
 int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, uint64_t *scratch, void *stream);
+/* The fused pass for ONE Z-slab of a sharded stack: lo_fixed / hi_fixed say that the slab's first / last slice is a GLOBAL
+ * end slice, already packed and filled in `bits`; otherwise `below` / `above` (bit-packed (ny, wx) slices with the ORIGINAL
+ * content of the neighbour rank's adjacent slice) close the stencil and every slice of the slab is computed.  nz >= 2. */
+int tomo_pack_close_slab(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, const uint64_t *below,
+                         const uint64_t *above, int lo_fixed, int hi_fixed, void *stream);
 /* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
  * workspace: tomo_close_ends_workspace_words() uint64 words. */
 int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);

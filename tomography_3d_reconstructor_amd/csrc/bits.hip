@@ -133,8 +133,13 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
 #ifndef PC_U
 #define PC_U 4          // slices whose 16-byte loads are in flight together per lane
 #endif
+// Z-slab form: the stencil's neighbours of the first / last slice of a slab are slices of the ranks below / above, handed
+// in bit-packed (`below`, `above`: (ny, wx) words each, or null); a slab that holds a GLOBAL end slice has it packed and
+// filled in `bits` already (lo_fixed / hi_fixed) and does not recompute it.  Outputs slices za .. zb-1.
 __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
-                                                         int nx, int wx, int groups, int runs)
+                                                         int nx, int wx, int groups, int runs, int za, int zb, int lo_fixed,
+                                                         int hi_fixed, const u64 *__restrict__ below,
+                                                         const u64 *__restrict__ above)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
     const int y = (int)(rem / groups), g = (int)(rem - (int64_t)y * groups);
     const int x = g * 1024 + lane * 16, word = g * 16 + (lane >> 2);
     const bool inx = x < nx, inw = word < wx;
-    const int z0 = 1 + r * PC_ZR, z1 = (z0 + PC_ZR < nz - 1) ? z0 + PC_ZR : nz - 1;          // outputs z0 .. z1-1
+    const int z0 = za + r * PC_ZR, z1 = (z0 + PC_ZR < zb) ? z0 + PC_ZR : zb;                 // outputs z0 .. z1-1
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const int64_t slice_bytes = (int64_t)ny * nx, slice_words = (int64_t)ny * wx;
     const uint8_t *mp = mask + (int64_t)y * nx + x;
@@ -159,13 +164,16 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
         w |= __shfl_xor(w, 2, 64);
         return w;
     };
+    auto in_bits = [&](int z) -> bool { return (z == 0 && lo_fixed) || (z == nz - 1 && hi_fixed); };
     auto raw_of = [&](int z) -> u4 {
         u4 t = {0u, 0u, 0u, 0u};
-        if (z > 0 && z < nz - 1 && inx) t = __builtin_nontemporal_load((const u4 *)(mp + (int64_t)z * slice_bytes));
+        if (z >= 0 && z < nz && !in_bits(z) && inx) t = __builtin_nontemporal_load((const u4 *)(mp + (int64_t)z * slice_bytes));
         return t;
     };
     auto word_of = [&](int z, u4 t) -> u64 {
-        if (z == 0 || z == nz - 1) return inw ? bp[(int64_t)z * slice_words] : 0ull;
+        if (z < 0) return (below && inw) ? below[(int64_t)y * wx + word] : 0ull;
+        if (z >= nz) return (above && inw) ? above[(int64_t)y * wx + word] : 0ull;
+        if (in_bits(z)) return inw ? bp[(int64_t)z * slice_words] : 0ull;
         return from_raw(t);
     };
     u64 prev = word_of(z0 - 1, raw_of(z0 - 1));
@@ -652,7 +660,29 @@ TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, i
     const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs);
+                       groups, runs, 1, nz - 1, 1, 1, (const u64 *)nullptr, (const u64 *)nullptr);
+    return tomo_status();
+}
+
+// The fused pass for ONE Z-slab of a sharded stack (slab.py): mask = the slab's nz slices, bits = its bit volume.
+// lo_fixed / hi_fixed: the slab's first / last slice is a GLOBAL end slice, already packed and filled in `bits` (kept);
+// otherwise the neighbour slice `below` / `above` (bit-packed (ny, wx), ORIGINAL content, from the rank below / above) closes
+// the stencil and every slice of the slab is computed.  Same layout requirements as tomo_pack_close_ends; nz >= 2.
+TOMO_API int tomo_pack_close_slab(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, const uint64_t *below,
+                                  const uint64_t *above, int lo_fixed, int hi_fixed, void *stream)
+{
+    if (!mask || !bits || nz < 2 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    if ((!lo_fixed && !below) || (!hi_fixed && !above)) return TOMO_E_ARG;
+    if (nx % 16 != 0 || (((uintptr_t)mask) & 15) != 0) return TOMO_E_ARG;
+    const int wx = (int)tomo_words_per_row(nx);
+    const int groups = (wx + 15) / 16;
+    const int za = lo_fixed ? 1 : 0, zb = hi_fixed ? nz - 1 : nz;
+    if (zb <= za) return TOMO_OK;
+    const int runs = (zb - za + PC_ZR - 1) / PC_ZR;
+    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
+                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above);
     return tomo_status();
 }
 

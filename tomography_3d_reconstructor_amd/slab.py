@@ -221,6 +221,34 @@ class HipEngine:
         buf = torch.empty((nzl + 2 * room, ny, wx), dtype=torch.int64, device=mask.device)
         return buf, pipeline.pack(mask, out=buf[room:room + nzl])
 
+    def pack_closed_slab(self, mask, room, comm, first, last):
+        """np.stack + _close_volume_ends for this rank's slices in ONE pass over its mask (pipeline.pack_closed's slab form):
+        the first and last slice are packed alone (and filled where they are global end slices), their ORIGINAL content goes
+        to the neighbours, and the fused kernel packs everything else with the neighbours' slices closing the stencil.
+        -> (halo buffer (nzl + 2 room, ny, words), bits of the closed slab = its middle), or None if the layout needs the
+        separate kernels (nx % 16 != 0, fewer than 2 slices)."""
+        from . import _lib
+        L = _lib.lib()
+        nzl, ny, nx = mask.shape
+        if nzl < 2 or nx % 16 != 0 or mask.data_ptr() % 16 != 0 or not pipeline.PACK_CLOSE_FUSED:
+            return None
+        st = torch.cuda.current_stream().cuda_stream
+        wx = L.tomo_words_per_row(nx)
+        buf = torch.empty((nzl + 2 * room, ny, wx), dtype=torch.int64, device=mask.device)
+        own = buf[room:room + nzl]
+        for z in (0, nzl - 1):
+            _lib.check(L.tomo_pack_bits(mask[z].data_ptr(), own[z].data_ptr(), 1, ny, nx, st), "tomo_pack_bits")
+        scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=mask.device)
+        if first:
+            _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, 0, scratch.data_ptr(), st), "tomo_fill_holes_slice")
+        if last:
+            _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, nzl - 1, scratch.data_ptr(), st), "tomo_fill_holes_slice")
+        below, above = comm.exchange(own[:1], own[nzl - 1:], torch.int64)
+        _lib.check(L.tomo_pack_close_slab(mask.data_ptr(), own.data_ptr(), nzl, ny, nx,
+                                          None if below is None else below.data_ptr(), None if above is None else above.data_ptr(),
+                                          1 if first else 0, 1 if last else 0, st), "tomo_pack_close_slab")
+        return buf, own
+
     def bits(self, vol):
         return vol.bits
 
@@ -392,11 +420,17 @@ class SlabJob:
         nzl = self.z1 - self.z0
         H = self.halo
         buf = None
-        if self.world > 1 and hasattr(e, "pack_into"):
-            buf, vol = e.pack_into(mask, H)                 # the slab in the middle of its halo-extended buffer
+        fused = None
+        if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
+            fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, H, c, first, last)
+        if fused is not None:
+            buf, bits = fused                               # packed and closed in one pass over the mask
         else:
-            vol = e.pack(mask)
-        bits = self._close_ends(vol, buf, H) if self.close_ends else e.bits(vol)
+            if self.world > 1 and hasattr(e, "pack_into"):
+                buf, vol = e.pack_into(mask, H)             # the slab in the middle of its halo-extended buffer
+            else:
+                vol = e.pack(mask)
+            bits = self._close_ends(vol, buf, H) if self.close_ends else e.bits(vol)
         closed = e.from_bits(bits, (nzl, self.ny, self.nx))
         # halo for morphology + Gaussian
         if self.world > 1:
