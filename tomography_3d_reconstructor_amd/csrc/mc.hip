@@ -46,6 +46,19 @@ typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));      // o
 typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
 typedef u32 u32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
+// q = a / b, returns a % b, for 0 <= a and 0 < b < 2^31: 32-bit division whenever a fits (rows, segments and tasks of every
+// volume the path meets do; a 64-bit division costs the GPU ~100 VALU instructions, and these sit in per-lane prologues)
+__device__ static inline int divmod_pos(int64_t a, int b, int64_t *q)
+{
+    if ((u64)a <= 0xffffffffull) {
+        const u32 qa = (u32)a / (u32)b;
+        *q = (int64_t)qa;
+        return (int)((u32)a - qa * (u32)b);
+    }
+    *q = a / b;
+    return (int)(a - *q * b);
+}
+
 __device__ static inline u64 make_key(int64_t row, int X, int slot)
 {
     return ((u64)row << (KEY_XBITS + 2)) | ((u64)(u32)X << 2) | (u64)slot;
@@ -64,10 +77,10 @@ __global__ __launch_bounds__(256) void field_signs_kernel(const float *__restric
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (Z - z_begin, s, Y), Y fastest
     if (task >= ntasks) return;
-    const int Y = (int)(task % g.Ny);
-    const int64_t tz = task / g.Ny;
-    const int s = (int)(tz % g.segs_per_row);
-    const int Z = z_begin + (int)(tz / g.segs_per_row);
+    int64_t tz, zq;
+    const int Y = divmod_pos(task, g.Ny, &tz);
+    const int s = divmod_pos(tz, g.segs_per_row, &zq);
+    const int Z = z_begin + (int)zq;
     const int X0 = s * SEG + lane * 4 - SEG_SHIFT - g.xorg;
     const int64_t NyP = tomo_sign_rows_dev(g.Ny);
     const float *row = field + ((int64_t)Z * g.Ny + Y) * g.pitch + g.xorg;
@@ -110,10 +123,10 @@ __global__ __launch_bounds__(256) void mc_classify_bits_kernel(const u64 *__rest
 {
     const int64_t task = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (Z, s, Y), Y fastest
     if (task >= ntasks) return;
-    const int Y = (int)(task % g.Ny);
-    const int64_t tz = task / g.Ny;
-    const int s = (int)(tz % g.segs_per_row);
-    const int Z = (int)(tz / g.segs_per_row);
+    int64_t tz, zq;
+    const int Y = divmod_pos(task, g.Ny, &tz);
+    const int s = divmod_pos(tz, g.segs_per_row, &zq);
+    const int Z = (int)zq;
     const int S = g.segs_per_row;
     const int Yn = Y + 1 < g.Ny ? Y + 1 : g.Ny - 1, Z1 = Z + 1 < g.Nz ? Z + 1 : g.Nz - 1;
     const int Xbase = s * SEG - SEG_SHIFT - g.xorg;      // X of (lane 0, k 0)
@@ -309,8 +322,8 @@ __global__ __launch_bounds__(256) void mc_list_kernel(const McGrid g, const u32 
     if (seg >= nseg) return;
     if (seg_aoff[seg + 1] == seg_aoff[seg]) return;             // empty: its ballot record was never written
     if (seg_aoff[seg + 1] > cap) return;                        // (capped call) the list is longer than the buffer: the caller redoes it
-    int s = (int)(seg % g.segs_per_row);
-    int64_t row = seg / g.segs_per_row;
+    int64_t row;
+    int s = divmod_pos(seg, g.segs_per_row, &row);
     const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
     ulonglong2 lo = q[0], hi = q[1];
     u64 b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
@@ -374,8 +387,9 @@ __device__ static inline void load_cell(const float *__restrict__ field, const M
 {
     c.row = (int64_t)(key >> (KEY_XBITS + 2));
     c.X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
-    c.Y = (int)(c.row % g.Ny);
-    c.Z = (int)(c.row / g.Ny);
+    int64_t zq;
+    c.Y = divmod_pos(c.row, g.Ny, &zq);
+    c.Z = (int)zq;
     int X1 = c.X + 1 < g.Nx ? c.X + 1 : g.Nx - 1;
     int Y1 = c.Y + 1 < g.Ny ? c.Y + 1 : g.Ny - 1;
     int Z1 = c.Z + 1 < g.Nz ? c.Z + 1 : g.Nz - 1;
@@ -899,8 +913,8 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_list_kernel(const McGrid g, const
     if (seg == nseg - 1) seg_aoff[nseg] = o + cnt;
     if (cnt == 0) return;                                       // empty: its ballot record was never written
     if (o + cnt > cap) { if (o <= cap) atomicOr((unsigned long long *)&tot[3], 1ull); return; }   // the list does not fit: flagged, nothing written
-    const int s = (int)(seg % g.segs_per_row);
-    const int64_t row = seg / g.segs_per_row;
+    int64_t row;
+    const int s = divmod_pos(seg, g.segs_per_row, &row);
     const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
     const ulonglong2 lo = q[0], hi = q[1];
     const u64 b0 = lo.x, b1 = lo.y, b2 = hi.x, b3 = hi.y;
@@ -1098,7 +1112,8 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_vertices_kernel(const McGrid g, c
     const u64 key = vox_key[i];
     const int64_t row = (int64_t)(key >> (KEY_XBITS + 2));
     const int X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
-    const int Y = (int)(row % g.Ny), Z = (int)(row / g.Ny);
+    int64_t zq;
+    const int Y = divmod_pos(row, g.Ny, &zq), Z = (int)zq;
     const u32 l = vox_loc[i];
     const u32 *sliceA = slice_tab, *sliceB = slice_tab + (g.Nz + 1);
     u32 dA = sliceB[Z] + blk3[i >> 8] + MC3_LOC_A(l);                // in-plane vertices of slice Z start at sliceA[Z] + sliceB[Z]
