@@ -11,6 +11,8 @@ bad = 0
 shapes = [(int(rng.integers(2, 30)), int(rng.integers(2, 70)), int(rng.integers(2, 300))) for _ in range(6)]
 for it in range(n):
     nz, ny, nx = shapes[it % len(shapes)] if it % 3 else (int(rng.integers(1, 30)), int(rng.integers(1, 70)), int(rng.integers(1, 300)))
+    if it % 4 == 1:
+        nx = max(16, nx // 16 * 16)                      # layouts the fused pack + close kernel takes
     kind = it % 3
     if kind == 0:
         v = rng.random((nz, ny, nx)) < 0.3 + 0.5 * rng.random()
@@ -30,14 +32,14 @@ for it in range(n):
     if ce:
         w = O.close_ends(w)
     w = O.smooth(w, iters, cm)
-    ref = O.SurfaceExtractor().extract_manifold_surface(w, depths, my, mx)
+    pad = bool(it % 5)
+    ref = O.SurfaceExtractor().extract_manifold_surface(w, depths, my, mx, True, True, pad)
     # device
-    vol = pipeline.pack(torch.from_numpy(np.ascontiguousarray(v).view(np.uint8)).to(dev))
-    if ce:
-        vol = pipeline.close_ends(vol)
+    mask = torch.from_numpy(np.ascontiguousarray(v).view(np.uint8)).to(dev)
+    vol = pipeline.pack_closed(mask) if ce else pipeline.pack(mask)      # one pass over the mask where the layout allows
     vol = pipeline.smooth(vol, iters, cm)
     ok = bool(np.array_equal(pipeline.unpack(vol).cpu().numpy().astype(bool), w))
-    got = pipeline.extract_surface(vol, depths, my, mx, True, True)
+    got = pipeline.extract_surface(vol, depths, my, mx, True, pad)
     if ref is None or got is None:
         ok &= (ref is None) == (got is None)
     else:
