@@ -217,8 +217,9 @@ def test_fill_holes_many_workgroups_vs_oracle(dev, shape, monkeypatch):
         _lib.check(L.tomo_fill_holes_ends(vol.bits.data_ptr(), 3, ny, nx, scratch.data_ptr(), None), "fill")
         got = to_np(vol)
         assert np.array_equal(got, exp), (name, "ends")
-        ctrl = scratch[:16].cpu().numpy()
-        assert ctrl[2] in (0, -1) and ctrl[10] in (0, -1), "a grid barrier of the band kernel was abandoned"
+        if not os.environ.get("TOMO_FILL_ONE_BLOCK"):          # (the one-workgroup kernel keeps its reach set in the scratch)
+            ctrl = scratch[:16].cpu().numpy()
+            assert ctrl[2] in (0, -1) and ctrl[10] in (0, -1), "a grid barrier of the band kernel was abandoned"
         vol1 = to_vol(v, dev)
         _lib.check(L.tomo_fill_holes_slice(vol1.bits.data_ptr(), 3, ny, nx, 0, scratch.data_ptr(), None), "fill")
         assert np.array_equal(to_np(vol1)[0], exp[0]) and np.array_equal(to_np(vol1)[2], v[2]), (name, "slice")
@@ -841,7 +842,9 @@ def test_mc3_chain_size_hints(dev):
     ref = {k: O.SurfaceExtractor().extract_manifold_surface(v, depths, 0.8, 1.1) for k, v in
            (("small", small), ("big", big), ("mid", mid), ("empty", empty))}
     vols = {"small": small, "big": big, "mid": mid, "empty": empty}
-    assert pipeline.MC3 and pipeline.NA_HINTS
+    if not pipeline.MC3:
+        pytest.skip("TOMO_MC_PATH=old: the round-1 kernels are selected")
+    assert pipeline.NA_HINTS
     pipeline._MC3_HINT.clear()
     c0 = dict(pipeline.COUNTERS)
     for k in ["small", "small", "big", "big", "mid", "small", "empty", "big", "empty", "mid"]:
