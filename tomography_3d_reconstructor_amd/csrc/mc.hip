@@ -1107,18 +1107,22 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_vertices_kernel(const McGrid g, c
 {
     const int64_t i = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
     if (tot[3] != 0 || i >= cap || (u64)i >= tot[0]) return;
+    // everything this lane needs from the list is fetched up front (independent, coalesced loads in flight together); only
+    // the two slice-table entries depend on one of them
     const int flags = vox_flags[i];
-    if (!flags) return;
     const u64 key = vox_key[i];
+    const u32 l = vox_loc[i];
+    const float3u f3 = *(const float3u *)(vox_f3 + 3 * i);
+    const u32 bA = blk3[i >> 8], bB = blk3[nblk + (i >> 8)];
     const int64_t row = (int64_t)(key >> (KEY_XBITS + 2));
     const int X = (int)((key >> 2) & ((1u << KEY_XBITS) - 1u));
     int64_t zq;
     const int Y = divmod_pos(row, g.Ny, &zq), Z = (int)zq;
-    const u32 l = vox_loc[i];
     const u32 *sliceA = slice_tab, *sliceB = slice_tab + (g.Nz + 1);
-    u32 dA = sliceB[Z] + blk3[i >> 8] + MC3_LOC_A(l);                // in-plane vertices of slice Z start at sliceA[Z] + sliceB[Z]
-    u32 dB = sliceA[Z + 1] + blk3[nblk + (i >> 8)] + MC3_LOC_B(l);   // between-plane ones after all in-plane ones of the slice
-    const float3u f3 = *(const float3u *)(vox_f3 + 3 * i);
+    const u32 sB = sliceB[Z], sA1 = sliceA[Z + 1];
+    if (!flags) return;
+    u32 dA = sB + bA + MC3_LOC_A(l);                                 // in-plane vertices of slice Z start at sliceA[Z] + sliceB[Z]
+    u32 dB = sA1 + bB + MC3_LOC_B(l);                                // between-plane ones after all in-plane ones of the slice
     const float fZ = (float)(Z + z_offset), fY = (float)Y, fX = (float)X;
     const u32 id = (u32)i * 4u;
     if (flags & 1) mc3_put_vertex(fZ, fY, f3.z, id, dA++, false, fin, vrec, keys, idx);
