@@ -697,7 +697,7 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
     m = Mc3Surface()
     m._f, m._seg_act, m._seg_aoff, m._tot = f, seg_act, seg_aoff, tot
 
-    def list_and_eval(cap):
+    def build_list(cap):
         m._cap = cap
         m._vox_key = torch.empty(cap, dtype=torch.int64, device=dev)
         _lib.check(L.tomo_mc3_list(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_cnt), _p(seg_act), _p(seg_blk), _p(seg_aoff), _p(m._vox_key), cap,
@@ -738,7 +738,7 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         # everything is enqueued into buffers of hint + 25 % before any count is known; ONE download at the end
         cap, cap_v, cap_f = (int(h * 1.25) + 4096 for h in hint)
         if cap < LIST_LIMIT and cap < 2 ** 29 and cap_v < MESH_LIMIT and cap_f < MESH_LIMIT:
-            list_and_eval(cap)
+            build_list(cap)
             eval_scan(cap, cap_v, cap_f)
             vertices_sort(cap, cap_v)
             m._cap_f = cap_f
@@ -751,13 +751,13 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
             else:
                 COUNTERS["mc3_hint_hit"] = COUNTERS.get("mc3_hint_hit", 0) + 1
     if host is None:
-        list_and_eval(1 << 16)                                   # a token buffer: tot[0] comes out exact, nothing is written past it
+        build_list(1 << 16)                                   # a token buffer: tot[0] comes out exact, nothing is written past it
         na = _download_tot(tot)[0]
         if na == 0:
             return None
         if na >= LIST_LIMIT or na >= 2 ** 29:
             raise _lib.TomoError("surface too large for 32-bit indices")
-        list_and_eval(na)
+        build_list(na)
         eval_scan(na, 2 ** 31 - 2, 2 ** 31 - 2)
         host = _download_tot(tot)
         nv, nf = host[1], host[2]
