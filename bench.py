@@ -148,6 +148,14 @@ class FieldTimer:
         return float(sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs))
 
 
+def one_pass(mask, depths):
+    """One pass of the hot path on a device-resident uint8 mask stack (what a bench step does on one GPU; tools/ use it)."""
+    from tomography_3d_reconstructor_amd import pipeline
+    vol = pipeline.pack_closed(mask)                   # np.stack + _close_volume_ends, one pass over the mask
+    vol = pipeline.smooth(vol, 3, True)
+    return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
+
+
 def cpu_baseline(n):
     from oracle import oracle as O
     masks = O.ellipsoid_masks(n, n, n)
@@ -247,9 +255,7 @@ def run(args, world):
         depths = np.full(gz, 1.0)
 
         def step():
-            vol = pipeline.pack_closed(mask)                   # np.stack + _close_volume_ends, one pass over the mask
-            vol = pipeline.smooth(vol, 3, True)
-            return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
+            return one_pass(mask, depths)
         parallelism = "single"
         workload = "%dx%dx%d ellipsoid stack" % (nx, ny, gz)
     if wname in CONFIG_INDEX and (gz, ny, nx) == WORKLOADS[wname]:

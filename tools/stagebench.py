@@ -13,11 +13,22 @@ else:
 dev = torch.device("cuda:0")
 mask = pipeline.ellipsoid_mask(nz, ny, nx, dev).view(torch.uint8)
 depths = np.full(nz, 1.0)
-stages = ["pack", "close", "smooth", "field", "mc", "finalize", "unique"]
+stages = ["pack+close", "smooth", "field", "mc3 chain"] if pipeline.MC3 else ["pack", "close", "smooth", "field", "mc", "finalize", "unique"]
 acc = {s: [] for s in stages}
 for it in range(6):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)]
     ev[0].record()
+    if pipeline.MC3:                                       # the production chain (TOMO_MC_PATH=old times the round-1 stages)
+        vol = pipeline.pack_closed(mask); ev[1].record()
+        vol = pipeline.smooth(vol, 3, True); ev[2].record()
+        f = pipeline.make_field(vol, True, True); ev[3].record()
+        m = pipeline.mc3_vertices(f, depths, 1.0, 1.0, True); ev[4].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            for k, s in enumerate(stages):
+                acc[s].append(ev[k].elapsed_time(ev[k + 1]))
+        del f, m, vol
+        continue
     vol = pipeline.pack(mask); ev[1].record()
     vol = pipeline.close_ends(vol, inplace=True); ev[2].record()
     vol = pipeline.smooth(vol, 3, True); ev[3].record()
