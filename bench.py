@@ -197,6 +197,46 @@ def host_to_host(mask_dev, nz):
     return times, shape
 
 
+def two_in_flight(mask, depths, passes):
+    """Side measurement (never `value`): two stacks in flight on ONE GPU -- two host threads, each with its own HIP stream,
+    each running whole passes on the same resident stack; the latency-bound marching-cubes chain of one overlaps the
+    bandwidth-bound stages of the other, and neither waits for the other's host round trip."""
+    import threading
+    import torch
+    dev = mask.device
+    bar = threading.Barrier(3)
+    errs = []
+
+    def worker():
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    one_pass(mask, depths)
+                s.synchronize()
+                bar.wait()
+                for _ in range(passes):
+                    one_pass(mask, depths)
+                s.synchronize()
+            bar.wait()
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+    th = [threading.Thread(target=worker) for _ in range(2)]
+    for t in th:
+        t.start()
+    try:
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = None
+    for t in th:
+        t.join()
+    return None if (errs or dt is None) else dt / (2 * passes) * 1e3
+
+
 def run(args, world):
     import datetime
     import numpy as np
@@ -361,6 +401,11 @@ def run(args, world):
         out["cold_pass_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         out["cold_pass_note"] = "one pass with the marching-cubes size hints and path counters cleared (allocator warm)"
         del r
+        tif = two_in_flight(mask, depths, max(4, min(args.steps, 10)))
+        if tif is not None:
+            out["two_in_flight_ms_per_pass"] = round(tif, 3)
+            out["two_in_flight_note"] = ("side measurement, never `value`: two host threads / HIP streams, whole passes on the same "
+                                         "resident stack (`value` runs the passes one after the other on one stream)")
         if total_voxels <= 2 ** 31:
             times, shape = host_to_host(mask, gz)
             out["host_to_host_ms"] = round(min(times), 2)
