@@ -372,7 +372,11 @@ def run(args, world):
             "halo_bytes_per_pass_all_ranks": int(agg[0].item() / steps), "halo_bytes_per_pass_max_rank": int(mx[1].item() / steps),
             "comm_calls_per_pass_per_rank": round(agg[1].item() / steps / world, 1),
             "comm_ms_per_pass_max_rank": round(mx[0].item() / steps * 1e3, 3),
-            "comm_ms_note": "host wall time inside exchange/all_gather calls, includes waiting for the kernels that produce the halos"})
+            "comm_ms_note": "host wall time inside exchange/all_gather calls, includes waiting for the kernels that produce the halos",
+            "numbering": {"deferred_passes": job.deferred_passes, "redone": job.deferred_redone,
+                          "note": "rank 0, warm-up included: passes that ran with ONE download at the end (chain from size hints, "
+                                  "shared-plane rows in fixed-capacity messages, global indices from device-side counts); the "
+                                  "first pass of a job is always the exact one (four host round trips)"}})
     pass_floor_bytes = 5.0 * total_voxels            # 1 B mask in + 4 B f32 field out per voxel: what a pass cannot avoid moving
     out = {
         "metric": "Mvoxels/s (SDF+MC) on 1024^3 ellipsoid stack; achieved HBM GB/s vs peak",

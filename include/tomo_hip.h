@@ -251,6 +251,10 @@ int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v);
 int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
                        unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
                        void *stream);
+/* The same, and tot[7] = number of rows with z' == z_top (the plane a Z-slab rank shares with the rank above; NaN: none). */
+int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+                           unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
+                           float z_top, void *stream);
 int tomo_mc3_faces(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
                    const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,
                    const uint16_t *vox_used, const uint32_t *blk3, const int32_t *table, int64_t *faces, int64_t cap_f,
@@ -286,6 +290,24 @@ int64_t tomo_mesh_faces_workspace_bytes(int64_t nf);
  * counter the caller zeroes) if it is not there.  Used by the Z-slab job for the shared-plane vertices. */
 int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t nq, int32_t *out,
                      unsigned long long *missing, void *stream);
+/* Z-slab numbering without host round trips (scale-out of the path; no counterpart in the single-process
+ * reference): all counts come from `tot` of the rank's mc3 chain (tot[1] rows, tot[7] of them on the shared top plane).
+ *   tomo_slab_top_rows  msg float32[(cap + 1) * 3]: row 0 = {n_top as uint32 bits, 0, 0}, then the top-plane rows, zero padded
+ *   tomo_slab_lookup    out[i] = index of row i of a received message in this rank's uniq, -1 past its count or when the
+ *                       row is not there (then *missing += 1; zeroed by the caller)
+ *   tomo_slab_summary   out int64[8] = kept rows | missing | flags (1 chain overflow, 2 rows not strictly ascending,
+ *                       4 n_top > cap_top, 8 caller_flags != 0) | rows | top rows | rows announced from below | list length |
+ *                       triangles -- what the ranks all-gather
+ *   tomo_slab_table     out[i] = GLOBAL index of the row table[i] names: own rows by position + this rank's offset (the
+ *                       sum of the lower ranks' kept rows in `gathered`, int64[world][8]), top-plane rows through ids_next
+ *                       (what the upper rank's tomo_slab_lookup found) + the upper rank's offset */
+int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream);
+int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
+                     int32_t *out, unsigned long long *missing, void *stream);
+int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, const unsigned long long *missing,
+                      int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream);
+int tomo_slab_table(const int32_t *table, int64_t n, const unsigned long long *tot, int64_t cap_v, const int64_t *gathered,
+                    int rank, int world, const int32_t *ids_next, int64_t cap_top, int32_t *out, void *stream);
 int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                     unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* Speculative one-pass variant: faces_out[f] = rank[faces32[f]] for every face (int64), totals[1] = nf, and totals[3]

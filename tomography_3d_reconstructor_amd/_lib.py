@@ -82,6 +82,7 @@ SIGNATURES = {
                                  _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "tomo_mc3_sort_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mc3_sort_rank": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "tomo_mc3_sort_rank_top": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_p]),
     "tomo_mc3_faces": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),
@@ -89,6 +90,10 @@ SIGNATURES = {
     "tomo_mesh_unique_presorted": (_c_i, [_c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mesh_faces_workspace_bytes": (_c_i64, [_c_i64]),
     "tomo_mesh_lookup": (_c_i, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "tomo_slab_top_rows": (_c_i, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tomo_slab_lookup": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "tomo_slab_summary": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tomo_slab_table": (_c_i, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p]),
     "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mesh_faces_direct": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tomo_mesh_volume_area": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_p]),

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void uq3_merge_kernel(const float4 *__restrict
 
 __global__ __launch_bounds__(256) void uq3_rank_kernel(const float4 *__restrict__ vrec, int64_t cap_v, const UqOrder ord,
                                                        float *__restrict__ uniq, int32_t *__restrict__ table,
-                                                       u64 *__restrict__ tot)
+                                                       u64 *__restrict__ tot, const float z_top)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool viol = false;
@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256) void uq3_rank_kernel(const float4 *__restrict_
     }
     const u64 n = (u64)__popcll(__ballot(viol));
     if ((threadIdx.x & 63) == 0 && n) atomicAdd((unsigned long long *)&tot[4], (unsigned long long)n);
+    // rows on the plane z' == z_top (a Z-slab rank's shared plane with the rank above; NaN: nobody asks) -> tot[7]
+    const u64 nt = (u64)__popcll(__ballot(live && a.x == z_top));
+    if ((threadIdx.x & 63) == 0 && nt) atomicAdd((unsigned long long *)&tot[7], (unsigned long long)nt);
 }
 
 struct Uq3Layout { size_t keys_alt, idx_alt, idx_merge, temp, temp_bytes, total; };
@@ -507,9 +510,9 @@ static Uq3Layout uq3_layout(int64_t cap_v)
 
 TOMO_API int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v) { return (int64_t)uq3_layout(cap_v).total; }
 
-TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
-                                unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
-                                void *stream)
+TOMO_API int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+                                    unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
+                                    float z_top, void *stream)
 {
     if (!vrec || !keys || !idx || !slice_tab || !tot || !uniq || !table || !workspace || cap_v <= 0 || Nz < 1) return TOMO_E_ARG;
     if (cap_v >= 0x7fffffffll || Nz > UQ_MAX_SLABS) return TOMO_E_SIZE;
@@ -530,8 +533,16 @@ TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx
         order.off = offsets;
     }
     hipLaunchKernelGGL(uq3_rank_kernel, dim3((unsigned)ceil_div64(cap_v, 256)), dim3(256), 0, s, (const float4 *)vrec, cap_v, order,
-                       uniq, table, (u64 *)tot);
+                       uniq, table, (u64 *)tot, z_top);
     return tomo_status();
+}
+
+TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+                                unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
+                                void *stream)
+{
+    return tomo_mc3_sort_rank_top(vrec, keys, idx, cap_v, Nz, slice_tab, tot, uniq, table, workspace, workspace_bytes,
+                                  __builtin_nanf(""), stream);
 }
 
 // ------------------------------------------------------------------------------------------ lookup
@@ -565,6 +576,139 @@ TOMO_API int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query,
     if (nu >= 0x7fffffffll) return TOMO_E_SIZE;
     hipLaunchKernelGGL(rows_lookup_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, (hipStream_t)stream, uniq, nu,
                        query, nq, out, (u64 *)missing);
+    return tomo_status();
+}
+
+// ------------------------------------------------------------------------------------------ Z-slab numbering on the device
+// A Z-slab rank (slab.py) numbers its vertices against its neighbours': the rows on the plane it shares with the rank above
+// close its sorted list (tot[7] of them, counted by uq3_rank_kernel), go up, are looked up there, and their indices come
+// back.  With the message capacities known from the last pass none of the counts has to reach the host before the triangles
+// are written: these four kernels take every count from device memory.
+//   message up   float32 (cap + 1, 3): row 0 = {number of rows as uint32 bits, 0, 0}, then the rows, zero padded
+//   summary      int64[8] per rank, all-gathered: kept rows | rows from below not found | flags | nv | n_top |
+//                rows announced from below | list length | triangles
+//                flags: 1 a chain buffer overflowed, 2 rows do not ascend strictly, 4 n_top > cap, 8 set by the caller
+__device__ static inline bool slab_counts_ok(const u64 *tot, int64_t cap_v)
+{
+    return tot[3] == 0 && tot[1] <= (u64)cap_v && tot[7] <= tot[1];
+}
+
+__global__ __launch_bounds__(256) void slab_top_rows_kernel(const float *__restrict__ uniq, const u64 *__restrict__ tot,
+                                                            int64_t cap_v, int64_t cap, float *__restrict__ msg)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = slab_counts_ok(tot, cap_v);
+    const u64 nv = ok ? tot[1] : 0, nt = ok ? tot[7] : 0;
+    if (i == 0) {
+        msg[0] = __uint_as_float((u32)(nt < 0xffffffffull ? nt : 0xffffffffull));
+        msg[1] = msg[2] = 0.f;
+    }
+    if (i >= cap) return;
+    float z = 0.f, y = 0.f, x = 0.f;
+    if ((u64)i < nt) {
+        const float *src = uniq + 3 * (nv - nt + (u64)i);
+        z = src[0]; y = src[1]; x = src[2];
+    }
+    msg[3 + 3 * i] = z; msg[4 + 3 * i] = y; msg[5 + 3 * i] = x;
+}
+
+__global__ __launch_bounds__(256) void slab_lookup_kernel(const float *__restrict__ uniq, const u64 *__restrict__ tot,
+                                                          int64_t cap_v, const float *__restrict__ msg, int64_t cap,
+                                                          int32_t *__restrict__ out, u64 *__restrict__ missing)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const int64_t nu = slab_counts_ok(tot, cap_v) ? (int64_t)tot[1] : 0;
+    const int64_t nq = (int64_t)__float_as_uint(msg[0]);
+    if (i >= nq) { out[i] = -1; return; }
+    const float qz = msg[3 + 3 * i], qy = msg[4 + 3 * i], qx = msg[5 + 3 * i];
+    int64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        const float *m = uniq + 3 * mid;
+        const bool less = m[0] < qz || (m[0] == qz && (m[1] < qy || (m[1] == qy && m[2] < qx)));
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    const bool found = lo < nu && uniq[3 * lo] == qz && uniq[3 * lo + 1] == qy && uniq[3 * lo + 2] == qx;
+    out[i] = found ? (int32_t)lo : -1;
+    if (!found) atomicAdd((unsigned long long *)missing, 1ull);
+}
+
+__global__ void slab_summary_kernel(const u64 *__restrict__ tot, int64_t cap_v, const float *__restrict__ msg_in,
+                                    const u64 *__restrict__ missing, int64_t cap_top, int64_t caller_flags,
+                                    int64_t *__restrict__ out)
+{
+    if (blockIdx.x | threadIdx.x) return;
+    int64_t flags = caller_flags ? 8 : 0;
+    if (tot[3] != 0 || tot[1] > (u64)cap_v || tot[7] > tot[1]) flags |= 1;
+    if (tot[4] != 0) flags |= 2;
+    if (tot[7] > (u64)cap_top) flags |= 4;
+    const int64_t from_prev = msg_in ? (int64_t)__float_as_uint(msg_in[0]) : 0;
+    out[0] = (flags & 1) ? 0 : (int64_t)(tot[1] - tot[7]);
+    out[1] = missing ? (int64_t)*missing : 0;
+    out[2] = flags;
+    out[3] = (int64_t)tot[1];
+    out[4] = (int64_t)tot[7];
+    out[5] = from_prev;
+    out[6] = (int64_t)tot[0];
+    out[7] = (int64_t)tot[2];
+}
+
+__global__ __launch_bounds__(256) void slab_table_kernel(const int32_t *__restrict__ table, int64_t n, const u64 *__restrict__ tot,
+                                                         int64_t cap_v, const int64_t *__restrict__ gathered, int rank,
+                                                         const int32_t *__restrict__ ids_next, int64_t cap_top,
+                                                         int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t off_me = 0;
+    for (int r = 0; r < rank; ++r) off_me += gathered[8 * r];
+    const int64_t off_next = off_me + gathered[8 * rank];
+    const bool ok = slab_counts_ok(tot, cap_v);
+    const int64_t nv = ok ? (int64_t)tot[1] : 0, k = nv - (ok ? (int64_t)tot[7] : 0);
+    int64_t row = table[i];                   // entries that belong to no vertex hold whatever was in memory
+    row = row < 0 ? 0 : (row >= nv ? (nv > 0 ? nv - 1 : 0) : row);
+    int64_t g;
+    if (row < k) g = row + off_me;
+    else {
+        const int64_t j = row - k;
+        g = off_next + ((ids_next && j < cap_top) ? (int64_t)ids_next[j] : 0);
+    }
+    out[i] = (int32_t)g;
+}
+
+TOMO_API int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream)
+{
+    if (!uniq || !tot || !msg || cap < 1 || cap_v < 1) return TOMO_E_ARG;
+    hipLaunchKernelGGL(slab_top_rows_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, uniq,
+                       (const u64 *)tot, cap_v, cap, msg);
+    return tomo_status();
+}
+
+TOMO_API int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
+                              int32_t *out, unsigned long long *missing, void *stream)
+{
+    if (!uniq || !tot || !msg || !out || !missing || cap < 1 || cap_v < 1) return TOMO_E_ARG;
+    hipLaunchKernelGGL(slab_lookup_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, uniq,
+                       (const u64 *)tot, cap_v, msg, cap, out, (u64 *)missing);
+    return tomo_status();
+}
+
+TOMO_API int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, const unsigned long long *missing,
+                               int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream)
+{
+    if (!tot || !out || cap_v < 1 || cap_top < 0) return TOMO_E_ARG;
+    hipLaunchKernelGGL(slab_summary_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const u64 *)tot, cap_v, msg_in,
+                       (const u64 *)missing, cap_top, caller_flags, out);
+    return tomo_status();
+}
+
+TOMO_API int tomo_slab_table(const int32_t *table, int64_t n, const unsigned long long *tot, int64_t cap_v, const int64_t *gathered,
+                             int rank, int world, const int32_t *ids_next, int64_t cap_top, int32_t *out, void *stream)
+{
+    if (!table || !tot || !gathered || !out || n < 1 || cap_v < 1 || rank < 0 || rank >= world) return TOMO_E_ARG;
+    hipLaunchKernelGGL(slab_table_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, table, n,
+                       (const u64 *)tot, cap_v, gathered, rank, ids_next, cap_top, out);
     return tomo_status();
 }
 

@@ -625,6 +625,17 @@ def _download_tot(tot):
     return [int(x) for x in host]
 
 
+def _download_vec(t):
+    """Any small int64 device vector in ONE transfer into page-locked memory -> list of ints."""
+    key = (str(t.device), threading.get_ident(), int(t.numel()))
+    host = _PINNED_TOT.get(key)
+    if host is None:
+        host = _PINNED_TOT[key] = torch.empty(t.numel(), dtype=torch.int64, pin_memory=True)
+    host.copy_(t.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.tolist()
+
+
 class Mc3Surface:
     """Vertices of a surface through the mc3 chain, ready for its triangles: `uniq` (U,3) float32 final rows in np.unique's
     order, `table` int32 (vertex id -> row index; id = 4 * list position of the owner voxel + slot).  faces(table) writes the
@@ -633,6 +644,7 @@ class Mc3Surface:
     def __init__(self):
         self.uniq = self.table = None
         self.nv = self.nf = self.na = 0
+        self.deferred = False       # True: enqueued into hint-sized buffers, no count has been read yet (see mc3_vertices)
 
     def faces(self, table=None, again=False):
         L = _lib.lib()
@@ -664,9 +676,29 @@ class Mc3Surface:
         return faces
 
 
-def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding=True, z_offset=0, with_faces=True):
+def _mc3_caps(hint):
+    """Buffer sizes of the hinted chain (last counts + 25 %), or None when they leave the 32-bit index range."""
+    if not hint:
+        return None
+    cap, cap_v, cap_f = (int(h * 1.25) + 4096 for h in hint)
+    if cap < LIST_LIMIT and cap < 2 ** 29 and cap_v < MESH_LIMIT and cap_f < MESH_LIMIT:
+        return cap, cap_v, cap_f
+    return None
+
+
+def mc3_hint_ready(f: Field, z_offset=0):
+    """Would mc3_vertices(f, ..., z_offset) run from size hints (no count read before everything is enqueued)?"""
+    return bool(NA_HINTS and _mc3_caps(_MC3_HINT.get((f.Nz, f.Ny, f.Nx, int(z_offset)))))
+
+
+def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding=True, z_offset=0, with_faces=True,
+                 z_top=None, defer=False):
     """surface_extractor.py:55-65 + :82-113 + the vertex half of :115-126 for a manifold=True field at level 0.5.
-    -> Mc3Surface (its .faces_final holds the triangles when with_faces), or None where the reference returns None."""
+    -> Mc3Surface (its .faces_final holds the triangles when with_faces), or None where the reference returns None.
+    z_top: also count the rows with z' == z_top into tot[7] (a Z-slab rank's plane shared with the rank above).
+    defer (with_faces=False only): when size hints exist, return right after enqueueing -- `.deferred` is set, no count has
+    been read, `_uniq` / `table` have the hinted capacities `_cap_v` / 4 `_cap` and the caller reads `_tot` itself
+    (slab.SlabJob._numbering_deferred); without hints the call behaves as usual."""
     L = _lib.lib()
     if min(f.Nz, f.Ny, f.Nx) < 2:
         return None
@@ -692,10 +724,11 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         adj_t = cum_t = None
         nadj = ncum = 0
     mmy, mmx = float(np.float32(mm_per_pixel_y)), float(np.float32(mm_per_pixel_x))
-    hint_key = (f.Nz, f.Ny, f.Nx)
+    hint_key = (f.Nz, f.Ny, f.Nx, int(z_offset))
     hint = _MC3_HINT.get(hint_key) if NA_HINTS else None
+    z_top = float("nan") if z_top is None else float(z_top)
     m = Mc3Surface()
-    m._f, m._seg_act, m._seg_aoff, m._tot = f, seg_act, seg_aoff, tot
+    m._f, m._seg_act, m._seg_aoff, m._tot, m._hint_key = f, seg_act, seg_aoff, tot, hint_key
 
     def build_list(cap):
         m._cap = cap
@@ -729,19 +762,24 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         _lib.check(L.tomo_mc3_vertices(f.Nz, f.Ny, f.Nx, f.xorg, _p(m._vox_key), cap, _p(tot), _p(m._vox_loc), _p(m._vox_flags),
                                        _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), _p(m._slice_tab), int(z_offset), 1, _p(cum_t), ncum,
                                        _p(adj_t), nadj, mmy, mmx, _p(m._vrec), _p(keys), _p(idx), st), "tomo_mc3_vertices")
-        _lib.check(L.tomo_mc3_sort_rank(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, _p(m._slice_tab), _p(tot), _p(m._uniq), _p(m.table),
-                                        _p(ws), wsb, st), "tomo_mc3_sort_rank")
+        m._cap_v = cap_v
+        _lib.check(L.tomo_mc3_sort_rank_top(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, _p(m._slice_tab), _p(tot), _p(m._uniq),
+                                            _p(m.table), _p(ws), wsb, z_top, st), "tomo_mc3_sort_rank_top")
 
     host = None
     faces = None
     if hint:
         # everything is enqueued into buffers of hint + 25 % before any count is known; ONE download at the end
-        cap, cap_v, cap_f = (int(h * 1.25) + 4096 for h in hint)
-        if cap < LIST_LIMIT and cap < 2 ** 29 and cap_v < MESH_LIMIT and cap_f < MESH_LIMIT:
+        caps = _mc3_caps(hint)
+        if caps:
+            cap, cap_v, cap_f = caps
             build_list(cap)
             eval_scan(cap, cap_v, cap_f)
             vertices_sort(cap, cap_v)
             m._cap_f = cap_f
+            if defer and not with_faces:
+                m.deferred = True
+                return m
             if with_faces:
                 faces = m.faces()
             host = _download_tot(tot)

@@ -13,7 +13,9 @@ cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, a
   cubes
   mesh         vertices on the shared plane are owned by the upper rank: rank r sends the coordinates of its
                top-plane vertices up, gets their indices back, and an all-gather of the per-rank unique counts
-               gives the global numbering.  Faces stay on their rank, in reference order.
+               gives the global numbering.  Faces stay on their rank, in reference order.  From a job's second pass
+               on none of this waits for the host (SlabJob._numbering_deferred: fixed-capacity messages, counts
+               taken from device memory, ONE download per pass; the exact pass is the fallback).
 
 The result is bit-identical to the single-GPU path (tests/test_slab_cpu.py with the CPU oracle as engine over
 gloo, tests/test_gpu_parity.py::test_slab_ranks_on_one_gpu_match_single_gpu with the HIP engine).
@@ -23,12 +25,15 @@ The class is written against two small interfaces so that the same orchestration
   comm   : rank, world, send(t, dst), recv(src), all_gather(t)
   engine : the device operations (HIP kernels in production; tests may inject the CPU oracle)
 """
+import os
+
 import numpy as np
 import torch
 
 from . import pipeline
 
 HALO_BITS = 10   # 8 morphology passes + 2 slices for the 5-tap Gaussian along z
+DEFERRED_NUMBERING = os.environ.get("TOMO_SLAB_DEFERRED", "1") not in ("", "0")   # the pass with ONE download (A/B switch)
 
 
 # ----------------------------------------------------------------------------- communication
@@ -339,12 +344,52 @@ class HipEngine:
     def remap_faces(self, faces32, gid32):
         return pipeline.remap_faces(faces32, gid32)
 
-    def mc3_vertices(self, f, z_offset, depths, mm_y, mm_x):
+    def mc3_vertices(self, f, z_offset, depths, mm_y, mm_x, z_top=None, defer=False):
         """The production chain (pipeline.mc3_vertices): finalised, sorted, duplicate-free vertex rows of this slab plus
-        the table vertex id -> row index; the triangles are written later, through a table of GLOBAL indices."""
+        the table vertex id -> row index; the triangles are written later, through a table of GLOBAL indices.
+        z_top: the mapped z of the plane shared with the rank above (its rows are counted on the device); defer: return
+        without reading any count when size hints exist (SlabJob._numbering_deferred reads them, once, at the end)."""
         if not pipeline.MC3:
             return NotImplemented
-        return pipeline.mc3_vertices(f, depths, mm_y, mm_x, True, z_offset=z_offset, with_faces=False)
+        return pipeline.mc3_vertices(f, depths, mm_y, mm_x, True, z_offset=z_offset, with_faces=False, z_top=z_top, defer=defer)
+
+    def mc3_ready(self, f, z_offset):
+        return pipeline.mc3_hint_ready(f, z_offset)
+
+    # device side of the numbering without host round trips (csrc/mesh.hip "Z-slab numbering on the device")
+    def slab_top_rows(self, uniq, tot, cap_v, cap):
+        from . import _lib
+        msg = torch.empty((cap + 1) * 3, dtype=torch.float32, device=uniq.device)
+        _lib.check(_lib.lib().tomo_slab_top_rows(uniq.data_ptr(), tot.data_ptr(), cap_v, cap, msg.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "tomo_slab_top_rows")
+        return msg
+
+    def slab_lookup(self, uniq, tot, cap_v, msg, cap):
+        from . import _lib
+        out = torch.empty(cap, dtype=torch.int32, device=uniq.device)
+        miss = torch.zeros(1, dtype=torch.int64, device=uniq.device)
+        _lib.check(_lib.lib().tomo_slab_lookup(uniq.data_ptr(), tot.data_ptr(), cap_v, msg.data_ptr(), cap, out.data_ptr(),
+                                               miss.data_ptr(), torch.cuda.current_stream().cuda_stream), "tomo_slab_lookup")
+        return out, miss
+
+    def slab_summary(self, tot, cap_v, msg_in, miss, cap_top, caller_flags):
+        from . import _lib
+        out = torch.empty(8, dtype=torch.int64, device=tot.device)
+        _lib.check(_lib.lib().tomo_slab_summary(tot.data_ptr(), cap_v, None if msg_in is None else msg_in.data_ptr(),
+                                                None if miss is None else miss.data_ptr(), cap_top, caller_flags, out.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "tomo_slab_summary")
+        return out
+
+    def slab_table(self, table, n, tot, cap_v, gathered, rank, world, ids_next, cap_top):
+        from . import _lib
+        out = torch.empty(n, dtype=torch.int32, device=table.device)
+        _lib.check(_lib.lib().tomo_slab_table(table.data_ptr(), n, tot.data_ptr(), cap_v, gathered.data_ptr(), rank, world,
+                                              None if ids_next is None else ids_next.data_ptr(), cap_top, out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "tomo_slab_table")
+        return out
+
+    def download(self, t):
+        return pipeline._download_vec(t)
 
     # reductions of the consumers (volume_calculator.py:23-35, 59-94) on the resident bit volume
     def slice_counts(self, vol):
@@ -376,6 +421,11 @@ class SlabJob:
             raise ValueError("slab thinner than the halo (%d slices): use fewer ranks" % self.halo)
         self.active = None
         self.created = self.smoothed = self.mesh = None     # this rank's share of the last run(), for the consumers below
+        # the pass without host round trips (_numbering_deferred): agreed by ALL ranks in the last pass's all-gather, with the
+        # message capacities both neighbours derive from that pass's exact shared-plane counts
+        self._deferred_ok = False
+        self._cap_top = self._cap_prev = 0
+        self.deferred_passes = self.deferred_redone = 0
 
     # -- step 1: closed slab (bits tensor of the owned slices)
     def _close_ends(self, vol, buf=None, room=0):
@@ -468,9 +518,15 @@ class SlabJob:
         Za = 0 if first else self.z0 + 1            # global padded index of the first owned slice
         dev = mask.device
         if hasattr(e, "mc3_vertices"):
-            m = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x)
+            z_top = None if (last or self.world == 1) else self._z_top(slice_depths, dev)
+            deferred = self._deferred_ok and DEFERRED_NUMBERING and self.world > 1 and hasattr(e, "slab_table")
+            m = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=deferred)
             if m is not NotImplemented:
-                self.mesh = self._global_numbering_mc3(m, slice_depths, dev)
+                ready = m is not None and hasattr(e, "mc3_ready") and bool(e.mc3_ready(f, Za))
+                if deferred:
+                    self.mesh = self._numbering_deferred(m, f, Za, slice_depths, mm_y, mm_x, z_top, dev)
+                else:
+                    self.mesh = self._global_numbering_mc3(m, slice_depths, dev, ready)
                 return self.mesh
         mesh = e.marching_cubes(f, Za)
         vkey = ny = None
@@ -486,9 +542,23 @@ class SlabJob:
         return self.mesh
 
     # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
-    def _number_rows(self, uniq, slice_depths, dev):
+    def _z_top(self, slice_depths, dev):
+        """Mapped z (float32, through the vertex finalisation arithmetic) of padded plane z1 + 1: the plane this rank shares
+        with the rank above.  Depends on the depth table only: computed once per table."""
+        zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
+        if getattr(self, "_zb_key", None) != zkey:
+            zt = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
+            self._zb, self._zb_key = float(self.eng.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
+        return self._zb
+
+    @staticmethod
+    def _msg_cap(n):
+        return int(n * 1.25) + 64
+
+    def _number_rows(self, uniq, slice_depths, dev, ready=False):
         """uniq: this rank's sorted, duplicate-free vertex rows (nu, 3).  -> (the rows this rank keeps, gid int64 (nu,):
-        the GLOBAL index of every one of the nu rows).  Sets self.vertex_offset / self.n_vertices_global."""
+        the GLOBAL index of every one of the nu rows).  Sets self.vertex_offset / self.n_vertices_global.
+        ready: this rank could run its next pass from size hints; the all-gather below makes it a joint decision."""
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
         nu0 = nu = uniq.shape[0]
@@ -500,11 +570,7 @@ class SlabJob:
         # counted on the device, handed up as a device scalar, and ONE download brings this rank's and the lower rank's.
         nt = torch.zeros(1, dtype=torch.int64, device=dev)
         if not last and nu:
-            zkey = np.asarray(slice_depths, dtype=np.float64).tobytes()
-            if getattr(self, "_zb_key", None) != zkey:             # depends on the depth table only: once per table
-                zt = torch.tensor([[float(self.z1 + 1), 1.0, 1.0]], dtype=torch.float32, device=dev)
-                self._zb, self._zb_key = float(e.finalize_vertices(zt, slice_depths, 1.0, 1.0)[0, 0].item()), zkey
-            nt = (uniq[:, 0] == self._zb).sum().reshape(1).to(torch.int64)
+            nt = (uniq[:, 0] == self._z_top(slice_depths, dev)).sum().reshape(1).to(torch.int64)
         cnt_prev, _ = c.exchange(None, nt, torch.int64)
         pair = torch.cat([nt, cnt_prev.reshape(1) if cnt_prev is not None else torch.zeros_like(nt)]).cpu()
         n_top, n_from_prev = int(pair[0]), int(pair[1])
@@ -527,8 +593,11 @@ class SlabJob:
         # the kept counts give every rank its offset; the same all-gather tells every rank whether ANY rank found a row from
         # below that is new to it -- that rank merges the two sorted lists properly, which changes its count, and the counts
         # are gathered once more (rare with the HIP engine: the lower rank's shared-plane rows are this rank's own)
-        got = torch.stack(c.all_gather(torch.cat([torch.tensor([k], dtype=torch.int64, device=dev), miss]))).cpu()
+        got = torch.stack(c.all_gather(torch.cat([torch.tensor([k], dtype=torch.int64, device=dev), miss,
+                                                  torch.tensor([1 if ready else 0], dtype=torch.int64, device=dev)]))).cpu()
         counts, misses = [int(x) for x in got[:, 0]], [int(x) for x in got[:, 1]]
+        self._deferred_ok = all(int(x) for x in got[:, 2])
+        self._cap_top, self._cap_prev = self._msg_cap(n_top), self._msg_cap(n_from_prev)
         if any(misses):
             if misses[self.rank]:
                 merged, r2 = e.unique(torch.cat([uniq, prev_rows], 0).contiguous())
@@ -563,7 +632,7 @@ class SlabJob:
         kept, gid_rows = self._number_rows(uniq, slice_depths, dev)
         return kept, self._faces(faces32, gid_rows[rank.to(torch.int64)])
 
-    def _global_numbering_mc3(self, m, slice_depths, dev):
+    def _global_numbering_mc3(self, m, slice_depths, dev, ready=False):
         """The same for the mc3 chain: m.uniq are this rank's sorted unique rows, m.table maps a vertex id to its row; the
         triangles are written once, straight through the table of GLOBAL indices."""
         if m is None:                                              # no surface in this slab: still take part in the exchanges
@@ -571,12 +640,72 @@ class SlabJob:
             kept, _ = self._number_rows(empty, slice_depths, dev)
             return kept, torch.zeros((0, 3), dtype=torch.int64, device=dev)
         nu = m.uniq.shape[0]
-        kept, gid_rows = self._number_rows(m.uniq, slice_depths, dev)
+        kept, gid_rows = self._number_rows(m.uniq, slice_depths, dev, ready)
         if self.n_vertices_global >= 2 ** 31:
             raise pipeline._lib.TomoError("more than 2^31 vertices: the triangle table holds 32-bit indices")
         # entries of the table that belong to no vertex hold whatever was in memory: clamp before they index anything
         table_g = gid_rows.to(torch.int32)[m.table.clamp_(0, max(nu - 1, 0))]
         return kept, m.faces_checked(table_g, again=True)
+
+    def _numbering_deferred(self, m, f, Za, slice_depths, mm_y, mm_x, z_top, dev):
+        """_global_numbering_mc3 without a host round trip before the triangles are written: the chain ran from size hints
+        and has not been read (m.deferred), the shared-plane rows travel in messages of the capacity both neighbours took
+        from the last pass (count in the header row), the lookup, the offsets and the table of GLOBAL indices take every
+        count from device memory, and ONE download at the end brings this rank's counters and every rank's summary.
+        Anything that did not fit or is not exact -- on ANY rank: the summaries are all-gathered, so all ranks decide alike --
+        sends every rank through the exact pass once more.  Every rank issues the same three collective steps whatever its
+        own state (a rank whose chain came back resolved or empty flags that in its summary)."""
+        e, c = self.eng, self.comm
+        r, w = self.rank, self.world
+        first, last = r == 0, r == w - 1
+        live = m is not None and getattr(m, "deferred", False)
+        if live:
+            tot, uniq, cap_v = m._tot, m._uniq, m._cap_v
+        else:                                                     # stand-ins: no rows, "overflow" set so that no count is trusted
+            tot = torch.zeros(8, dtype=torch.int64, device=dev)
+            tot[3] = 1
+            uniq, cap_v = torch.zeros((1, 3), dtype=torch.float32, device=dev), 1
+        cap_top, cap_prev = (0 if last else self._cap_top), (0 if first else self._cap_prev)
+        token = torch.zeros(3, dtype=torch.float32, device=dev)
+        up = token if last else e.slab_top_rows(uniq, tot, cap_v, cap_top)
+        from_prev, _ = c.exchange(None, up, torch.float32, recv_shape_prev=((cap_prev + 1) * 3,))
+        idx_prev, miss = (None, None) if first else e.slab_lookup(uniq, tot, cap_v, from_prev, cap_prev)
+        summary = e.slab_summary(tot, cap_v, None if first else from_prev, miss, cap_top, 0 if live else 1)
+        gathered = torch.stack(c.all_gather(summary)).contiguous()
+        down = torch.zeros(1, dtype=torch.int32, device=dev) if first else idx_prev
+        _, ids_next = c.exchange(down, None, torch.int32, recv_shape_next=(cap_top,))
+        faces = None
+        if live:
+            table_g = e.slab_table(m.table, 4 * m._cap, tot, cap_v, gathered, r, w, None if last else ids_next, cap_top)
+            faces = m.faces(table_g)
+        host = e.download(torch.cat([tot.view(torch.int64).reshape(-1), gathered.reshape(-1)]))
+        own, g = host[:8], [host[8 + 8 * i:16 + 8 * i] for i in range(w)]
+        bad = any(row[1] or row[2] for row in g) or any(g[i][4] != g[i + 1][5] for i in range(w - 1))
+        if bad:
+            # rare: a hint or a message capacity was too small, rows that do not ascend strictly (the general sort decides),
+            # a row from below that is new here -- everybody takes the exact pass
+            self.deferred_redone += 1
+            self._deferred_ok = False
+            m2 = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=False)
+            ready = m2 is not None and bool(e.mc3_ready(f, Za))
+            return self._global_numbering_mc3(m2, slice_depths, dev, ready)
+        self.deferred_passes += 1
+        counts = [row[0] for row in g]
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        self.vertex_offset, self.n_vertices_global = int(offs[r]), int(offs[-1])
+        if self.n_vertices_global >= 2 ** 31:
+            raise pipeline._lib.TomoError("more than 2^31 vertices: the triangle table holds 32-bit indices")
+        if own[6]:
+            raise pipeline._lib.TomoError("internal error: %d triangle corners reference a missing vertex" % own[6])
+        m.na, m.nv, m.nf = own[0], own[1], own[2]
+        m.uniq = m._uniq[:m.nv]
+        pipeline._MC3_HINT[m._hint_key] = (max(m.na, 1), max(m.nv, 1), max(m.nf, 1))
+        self._cap_top, self._cap_prev = self._msg_cap(g[r][4]), self._msg_cap(g[r][5])
+        faces = faces[:m.nf]
+        if own[5]:
+            keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+            faces = faces[keep]
+        return m._uniq[:counts[r]], faces
 
     def _faces(self, faces32, gid):
         if faces32.shape[0] == 0:
