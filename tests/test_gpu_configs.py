@@ -107,6 +107,14 @@ def run_slab_threads(dev, mask, shape, depths, world, obj_path=None):
             job = slab.SlabJob(gz, ny, nx, c)
             with torch.cuda.stream(torch.cuda.Stream()):
                 verts, faces = job.run(mask[job.z0:job.z1].view(torch.uint8), depths, 1.0, 1.0)
+                if pipeline.MC3 and pipeline.NA_HINTS and slab.DEFERRED_NUMBERING:
+                    # once more: the second pass of a job runs without host round trips (one download at its end)
+                    first_pass = (verts, faces, job.vertex_offset, job.n_vertices_global)
+                    verts, faces = job.run(mask[job.z0:job.z1].view(torch.uint8), depths, 1.0, 1.0)
+                    assert (job.deferred_passes, job.deferred_redone) == (1, 0), (job.deferred_passes, job.deferred_redone)
+                    assert torch.equal(verts, first_pass[0]) and torch.equal(faces, first_pass[1])
+                    assert (job.vertex_offset, job.n_vertices_global) == first_pass[2:]
+                    del first_pass
                 extras = {"vol": job.voxel_volume(1.0, 1.0, depths), "box": job.bounding_box(1.0, 1.0, depths),
                           "vol_created": job.voxel_volume(1.0, 1.0, depths, "created")}
                 if obj_path is not None:
