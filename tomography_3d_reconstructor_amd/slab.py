@@ -6,11 +6,12 @@ cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, a
 
   close ends   c'[z] = c[z] | (c[z+1] & c'[z-1]) is the local stencil c[z] | (c[z-1] & c[z+1]): one ORIGINAL slice
                from either neighbour (one two-way exchange of one bit-packed slice), no carry from further away.
-  smoothing    8 passes of a radius-1 stencil + 2 slices for the Gaussian: one exchange of 10 bit-packed halo
-               slices per side, after which every pass runs locally (the contaminated rim shrinks into the halo).
+  smoothing    8 passes of a radius-1 stencil + 2 slices for the Gaussian: one exchange of 10 (from below) / 11 (from
+               above) bit-packed halo slices, after which every pass runs locally (the contaminated rim shrinks
+               into the halo).
   field        computed locally on the halo-extended slab; the owned field slices are exact.
-  marching     needs field slice z1 of rank r+1: THE one-slice float32 halo.
-  cubes
+  marching     needs field slice z1 of rank r+1: computed locally from one more bit-packed halo slice from above
+  cubes        (11 instead of 10; no float data travels).
   mesh         vertices on the shared plane are owned by the upper rank: rank r sends the coordinates of its
                top-plane vertices up, gets their indices back, and an all-gather of the per-rank unique counts
                gives the global numbering.  Faces stay on their rank, in reference order.  From a job's second pass
@@ -469,51 +470,48 @@ class SlabJob:
         first, last = self.rank == 0, self.rank == self.world - 1
         nzl = self.z1 - self.z0
         H = self.halo
+        Hu = H + 1          # one more slice from above: the field slice marching cubes needs beyond the slab is computed HERE
         buf = None
         fused = None
         if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
-            fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, H, c, first, last)
+            fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last)
         if fused is not None:
             buf, bits = fused                               # packed and closed in one pass over the mask
         else:
             if self.world > 1 and hasattr(e, "pack_into"):
-                buf, vol = e.pack_into(mask, H)             # the slab in the middle of its halo-extended buffer
+                buf, vol = e.pack_into(mask, Hu)            # the slab in the middle of its halo-extended buffer
             else:
                 vol = e.pack(mask)
-            bits = self._close_ends(vol, buf, H) if self.close_ends else e.bits(vol)
+            bits = self._close_ends(vol, buf, Hu) if self.close_ends else e.bits(vol)
         closed = e.from_bits(bits, (nzl, self.ny, self.nx))
-        # halo for morphology + Gaussian
+        # halo for morphology + Gaussian: H closed slices from below, H + 1 from above
         if self.world > 1:
-            lo, hi = c.exchange(bits[:H], bits[nzl - H:], torch.int64)
-            if buf is not None:
+            lo, hi = c.exchange(bits[:Hu], bits[nzl - H:], torch.int64)
+            if buf is not None:                             # room is Hu on either side: the lower halo leaves one slice unused
                 if not first:
-                    buf[:H].copy_(lo)
+                    buf[Hu - H:Hu].copy_(lo)
                 if not last:
-                    buf[H + nzl:].copy_(hi)
-                a0, b0 = (H if first else 0), H + nzl + (0 if last else H)
+                    buf[Hu + nzl:].copy_(hi)
+                a0, b0 = (Hu if first else Hu - H), Hu + nzl + (0 if last else Hu)
                 ext = e.from_bits(buf[a0:b0], (b0 - a0, self.ny, self.nx))
             else:
                 parts = ([] if first else [lo]) + [bits] + ([] if last else [hi])
-                ext = e.from_bits(torch.cat(parts, 0), (nzl + (0 if first else H) + (0 if last else H), self.ny, self.nx))
+                ext = e.from_bits(torch.cat(parts, 0), (nzl + (0 if first else H) + (0 if last else Hu), self.ny, self.nx))
         else:
             ext = closed
         sm = e.smooth(ext, self.iterations, self.create_manifold)
-        # keep 2 halo slices for the field
         sb = e.bits(sm)
         own = 0 if (first or self.world == 1) else H
         self.created, self.smoothed = closed, e.from_bits(sb[own:own + nzl], (nzl, self.ny, self.nx))
+        # the field of slices [z0 - 2, z1 + 3): exact on the owned slices AND on slice z1 -- the first owned slice of the
+        # rank above, the one field slice marching cubes reads beyond the slab (round 1 / the first half of round 2 sent it
+        # down as a float32 slice: 4 MB per neighbour and an exchange step, against one more bit-packed halo slice)
         a = 0 if first else H - 2
-        b = sb.shape[0] - (0 if last else H - 2)
+        b = sb.shape[0] - (0 if last else Hu - 3)
         fvol = e.from_bits(sb[a:b], (b - a, self.ny, self.nx))
         f = e.field(fvol)
-        # owned padded slices: local field index range [fa, fb); local slice fb (computed without its upper
-        # neighbourhood, hence wrong) is replaced by THE one-slice field halo: the first owned slice of rank+1
         fa = 0 if first else 3
-        fb = f.Nz - (0 if last else 3)
-        if self.world > 1:
-            _, top = c.exchange(e.field_slices(f, fa, fa + 1).data, None, torch.float32)
-            if not last:
-                e.field_set_slice(f, fb, top)
+        fb = f.Nz - (0 if last else 4)              # local index of slice z1 (not last) / one past the padded volume (last)
         f = e.field_slices(f, fa, fb + (0 if last else 1))
         Za = 0 if first else self.z0 + 1            # global padded index of the first owned slice
         dev = mask.device
