@@ -91,9 +91,6 @@ class OracleEngine:
     def field_slices(self, f, a, b):
         return OField(f.data[a:b])
 
-    def field_set_slice(self, f, z, slice_data):
-        f.data[z].copy_(slice_data.reshape(f.data.shape[1], f.data.shape[2]))
-
     def marching_cubes(self, f, z_offset):
         try:
             v, fc = O.marching_cubes(f.data.numpy(), 0.5, z_offset)

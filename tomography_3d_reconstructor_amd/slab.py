@@ -303,11 +303,6 @@ class HipEngine:
                               f.signs[a:b] if f.signs is not None else None, f.signs_level,
                               f.gcls[a:b] if f.gcls is not None else None)
 
-    def field_set_slice(self, f, z, slice_data):
-        f.data[z].copy_(slice_data.reshape(f.data.shape[1], f.data.shape[2]))
-        if f.signs is not None:
-            pipeline.field_signs(f, f.signs_level, z, z + 1)
-
     def marching_cubes(self, f, z_offset):
         return pipeline.marching_cubes(f, 0.5, z_offset)
 
