@@ -64,8 +64,8 @@ __device__ static inline u32 nonzero_nibble(u32 w)
 #define PACK_U 4        // 1024-voxel units per wave, their 16-byte loads in flight together.  Plain loads: 1: 4.8, 2: 5.2, 4: 5.0,
                         // 8: 4.6 TB/s; nontemporal loads (the mask is read exactly once): 1: 4.9, 2: 5.6, 4: 6.1 TB/s
 #endif
-__global__ __launch_bounds__(256) void pack16_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits,
-                                                     int64_t rows, int nx, int wx, int groups)
+__device__ __forceinline__ void pack16_body(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int64_t rows, int nx,
+                                            int wx, int groups)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -100,6 +100,22 @@ __global__ __launch_bounds__(256) void pack16_kernel(const uint8_t *__restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void pack16_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits,
+                                                     int64_t rows, int nx, int wx, int groups)
+{
+    pack16_body(mask, bits, rows, nx, wx, groups);
+}
+
+// The two end slices of a stack in ONE launch (blockIdx.y = 0 / 1: slice 0 / nz - 1), and the 16 control words of the
+// fill-holes kernel that runs next are cleared on the way (saves a launch and a 128-byte memset in front of every pass).
+__global__ __launch_bounds__(256) void pack16_ends_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int64_t rows,
+                                                          int nx, int wx, int groups, int64_t mask_step, int64_t bits_step,
+                                                          u64 *__restrict__ ctrl)
+{
+    if (ctrl && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) ctrl[threadIdx.x] = 0ull;
+    pack16_body(mask + (int64_t)blockIdx.y * mask_step, bits + (int64_t)blockIdx.y * bits_step, rows, nx, wx, groups);
+}
+
 TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, void *stream)
 {
     if (!mask || !bits || nz <= 0 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
@@ -132,6 +148,9 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
 #endif
 #ifndef PC_U
 #define PC_U 4          // slices whose 16-byte loads are in flight together per lane
+#endif
+#ifndef PC_PIPELINED
+#define PC_PIPELINED 1  // 0: every run through the generic loop (A/B)
 #endif
 // Z-slab form: the stencil's neighbours of the first / last slice of a slab are slices of the ranks below / above, handed
 // in bit-packed (`below`, `above`: (ny, wx) words each, or null); a slab that holds a GLOBAL end slice has it packed and
@@ -176,6 +195,58 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
         if (in_bits(z)) return inw ? bp[(int64_t)z * slice_words] : 0ull;
         return from_raw(t);
     };
+    // Fast path (all runs but the first and the last of a stack): every slice z0-1 .. z1 comes from the mask and the run is a
+    // whole number of groups of PC_U slices -- straight-line code, the loads of the NEXT group are issued before the current
+    // one is reduced and stored, so no wave ever waits for its own stores before it may load again (the generic loop below
+    // keeps its loads under the end-slice conditions and is left with s_waitcnt vmcnt(0) at the top of every iteration).
+    // Lanes past the row end read the row's first 16 bytes instead and contribute nothing.
+    if (PC_PIPELINED && z0 >= 1 && z1 <= nz - 1 && !in_bits(z0 - 1) && !in_bits(z1) && (z1 - z0) % PC_U == 0 && z1 > z0) {
+        const uint8_t *p = mask + (int64_t)y * nx + (inx ? x : 0) + (int64_t)(z0 - 1) * slice_bytes;
+        auto word_fast = [&](u4 t) -> u64 {
+            const u32 piece = nonzero_nibble(t.x) | (nonzero_nibble(t.y) << 4) | (nonzero_nibble(t.z) << 8) | (nonzero_nibble(t.w) << 12);
+            u64 w = (u64)(inx ? piece : 0u) << (16 * (lane & 3));
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            return w;
+        };
+        const u4 t_prev = __builtin_nontemporal_load((const u4 *)p);
+        const u4 t_cur = __builtin_nontemporal_load((const u4 *)(p + slice_bytes));
+        p += 2 * slice_bytes;
+        u4 t[PC_U];
+#pragma unroll
+        for (int j = 0; j < PC_U; j++) t[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
+        p += (int64_t)PC_U * slice_bytes;
+        u64 prev = word_fast(t_prev), cur = word_fast(t_cur);
+        u64 *q = bp + (int64_t)z0 * slice_words;
+        const bool st = (lane & 3) == 0 && inw;
+        const int groups_z = (z1 - z0) / PC_U;
+        for (int gz = 0; gz + 1 < groups_z; gz++) {
+            u4 n[PC_U];
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) n[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
+            p += (int64_t)PC_U * slice_bytes;
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) {
+                const u64 next = word_fast(t[j]);
+                const u64 out = cur | (prev & next);
+                if (st) q[(int64_t)j * slice_words] = out;
+                prev = cur;
+                cur = next;
+            }
+            q += (int64_t)PC_U * slice_words;
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) t[j] = n[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PC_U; j++) {
+            const u64 next = word_fast(t[j]);
+            const u64 out = cur | (prev & next);
+            if (st) q[(int64_t)j * slice_words] = out;
+            prev = cur;
+            cur = next;
+        }
+        return;
+    }
     u64 prev = word_of(z0 - 1, raw_of(z0 - 1));
     u64 cur = word_of(z0, raw_of(z0));
     for (int z = z0; z < z1; z += PC_U) {
@@ -600,7 +671,8 @@ static inline int fill_bands_plan(int ny, int wx, int *RB_out)
     return nb;
 }
 
-static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u64 *scratch, hipStream_t st)
+static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u64 *scratch, hipStream_t st,
+                             bool ctrl_cleared = false)
 {
     int RB = 0;
     const int nb = getenv("TOMO_FILL_ONE_BLOCK") ? 0 : fill_bands_plan(ny, wx, &RB);
@@ -611,7 +683,7 @@ static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u
         if (sliceB) hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceB, scratch, ny, nx, wx);
         return tomo_status();
     }
-    if (hipMemsetAsync(scratch, 0, 16 * sizeof(u64), st) != hipSuccess) return TOMO_E_LAUNCH;
+    if (!ctrl_cleared && hipMemsetAsync(scratch, 0, 16 * sizeof(u64), st) != hipSuccess) return TOMO_E_LAUNCH;
     FillBands p;
     p.slice[0] = sliceA; p.slice[1] = sliceB ? sliceB : sliceA;
     p.ctrl = scratch; p.comp = scratch + 16;
@@ -650,11 +722,11 @@ TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, i
     const int wx = (int)tomo_words_per_row(nx);
     if (wx > FH_THREADS) return TOMO_E_SIZE;
     const int groups = (wx + 15) / 16;
-    int rc = tomo_pack_bits(mask, bits, 1, ny, nx, stream);
-    if (rc) return rc;
-    rc = tomo_pack_bits(mask + (int64_t)(nz - 1) * ny * nx, bits + (int64_t)(nz - 1) * ny * wx, 1, ny, nx, stream);
-    if (rc) return rc;
-    rc = tomo_fill_holes_ends(bits, nz, ny, nx, scratch, stream);
+    hipLaunchKernelGGL(pack16_ends_kernel, dim3((unsigned)ceil_div64(ceil_div64((int64_t)ny * groups, PACK_U), 4), 2), dim3(256), 0,
+                       (hipStream_t)stream, mask, (u64 *)bits, (int64_t)ny, nx, wx, groups, (int64_t)(nz - 1) * ny * nx,
+                       (int64_t)(nz - 1) * ny * wx, (u64 *)scratch);
+    int rc = fill_holes_launch((u64 *)bits, (u64 *)bits + (int64_t)(nz - 1) * ny * wx, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream,
+                               true);
     if (rc) return rc;
     const int runs = (nz - 2 + PC_ZR - 1) / PC_ZR;
     const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
