@@ -81,6 +81,16 @@ int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, int ny, in
  * content of the neighbour rank's adjacent slice) close the stencil and every slice of the slab is computed.  nz >= 2. */
 int tomo_pack_close_slab(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, const uint64_t *below,
                          const uint64_t *above, int lo_fixed, int hi_fixed, void *stream);
+/* tomo_pack_close_slab for the output slices [z_from, z_to) only (the middle of a slab depends on the mask alone: a Z-slab
+ * rank enqueues it before it talks to its neighbours, the end ranges afterwards; `below` / `above` are needed only if the
+ * range reaches an end that is not fixed).  Any split of [0, nz) into ranges gives the same bits. */
+int tomo_pack_close_range(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, int z_from, int z_to,
+                          const uint64_t *below, const uint64_t *above, int lo_fixed, int hi_fixed, void *stream);
+/* The stencil on n bit-packed slices whose neighbours are given separately: out[i] = mid[i] | (prev & next), prev = i ?
+ * mid[i-1] : before, next = i < n-1 ? mid[i+1] : after ((ny, wx) words per slice; out must not overlap mid).  A Z-slab
+ * rank closes the ORIGINAL halo slices of its neighbours with it. */
+int tomo_close_stencil(const uint64_t *before, const uint64_t *mid, const uint64_t *after, int n, int ny, int nx,
+                       uint64_t *out, void *stream);
 /* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
  * workspace: tomo_close_ends_workspace_words() uint64 words. */
 int64_t tomo_close_ends_workspace_words(int nz, int ny, int nx);

@@ -194,3 +194,49 @@ def test_slab_kernels_take_counts_from_device_memory(dev):
     k = nv - nt
     exp = np.where(t < k, t + 1000, want[np.clip(t - k, 0, nt - 1)] + 1000 + k)
     assert np.array_equal(got, exp.astype(np.int32))
+
+
+@pytest.mark.parametrize("world,nz", [(2, 300), (3, 391)])
+def test_merged_edge_exchange_matches_single_gpu(dev, world, nz):
+    """Slabs of at least 4 * PC_EDGE slices take the one-exchange front: ORIGINAL edge slices travel while the middle of the
+    slab is packed + closed, every rank closes its neighbours' halo slices itself.  Noisy stack with holes in both end
+    slices and structure right at the slab boundaries; two passes (exact, deferred), meshes and closed / smoothed volumes
+    byte-identical to the single-GPU path."""
+    ny, nx = 40, 80
+    assert nz // world >= 4 * slab.PC_EDGE
+    rng = np.random.default_rng(nz)
+    v = blob(nz, ny, nx, 1.0, nz)
+    v ^= rng.random(v.shape) < 0.01
+    v[0, 4:30, 6:70] = True
+    v[0, 10:20, 20:40] = False
+    v[nz - 1, 8:36, 10:60] = True
+    v[nz - 1, 15:25, 25:45] = False
+    for r in range(1, world):                                            # alternating slices across every slab boundary
+        zb = slab.slab_range(nz, r, world)[0]
+        v[zb - 14:zb + 14:2, 5:35, 5:75] = True
+        v[zb - 13:zb + 14:2, 5:35, 5:75] = rng.random((14, 30, 70)) < 0.5
+    depths = np.full(nz, 0.5)
+    ref = single_gpu(v, depths, 1.0, 1.0, dev)
+    mask = torch.from_numpy(v.view(np.uint8)).to(dev)
+    created = pipeline.close_ends(pipeline.pack(mask))
+    smoothed = pipeline.smooth(created, 3, True)
+    ref_counts = (pipeline.slice_counts(created).cpu().numpy(), pipeline.slice_counts(smoothed).cpu().numpy())
+    counts = [None] * world
+    orig_run = slab.SlabJob.run
+
+    def run_and_count(self, *a, **k):
+        out = orig_run(self, *a, **k)
+        counts[self.rank] = (self.slice_counts("created"), self.slice_counts("smoothed"))
+        return out
+
+    slab.SlabJob.run = run_and_count
+    try:
+        out, stats = run_passes(world, [v, v], depths, 1.0, 1.0, dev)
+    finally:
+        slab.SlabJob.run = orig_run
+    for per_rank in out:
+        check_pass(per_rank, ref)
+    for c in counts:
+        assert np.array_equal(c[0], ref_counts[0]) and np.array_equal(c[1], ref_counts[1])
+    if pipeline.MC3 and pipeline.NA_HINTS and slab.DEFERRED_NUMBERING:
+        assert stats == [(1, 0)] * world, stats

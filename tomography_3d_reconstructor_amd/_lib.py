@@ -47,6 +47,8 @@ SIGNATURES = {
     "tomo_fill_holes_ends": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_close_ends": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_close_slab": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p]),
+    "tomo_close_stencil": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    "tomo_pack_close_range": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "tomo_close_ends_workspace_words": (_c_i64, [_c_i, _c_i, _c_i]),
     "tomo_close_ends_scan": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_close_ends_gp": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p]),

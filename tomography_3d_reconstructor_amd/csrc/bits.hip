@@ -736,6 +736,56 @@ TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, i
     return tomo_status();
 }
 
+// tomo_pack_close_slab for the output slices [z_from, z_to) only: the slices in the middle of a slab depend on nothing but
+// the mask, so a Z-slab rank enqueues them before it talks to its neighbours and the end ranges afterwards.  `below` /
+// `above` are needed only if the range reaches slice 0 / nz - 1 of a slab whose end is not fixed.  The run decomposition
+// starts at z_from: any split of [0, nz) into ranges gives the same bits.
+TOMO_API int tomo_pack_close_range(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, int z_from, int z_to,
+                                   const uint64_t *below, const uint64_t *above, int lo_fixed, int hi_fixed, void *stream)
+{
+    if (!mask || !bits || nz < 2 || ny <= 0 || nx <= 0 || z_from < 0 || z_to > nz) return TOMO_E_ARG;
+    if (nx % 16 != 0 || (((uintptr_t)mask) & 15) != 0) return TOMO_E_ARG;
+    const int za = z_from > (lo_fixed ? 1 : 0) ? z_from : (lo_fixed ? 1 : 0);
+    const int zb = z_to < (hi_fixed ? nz - 1 : nz) ? z_to : (hi_fixed ? nz - 1 : nz);
+    if (zb <= za) return TOMO_OK;
+    if ((za == 0 && !below) || (zb == nz && !above)) return TOMO_E_ARG;
+    const int wx = (int)tomo_words_per_row(nx);
+    const int groups = (wx + 15) / 16;
+    const int runs = (zb - za + PC_ZR - 1) / PC_ZR;
+    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
+                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above);
+    return tomo_status();
+}
+
+// The stencil alone, on n bit-packed slices with their two neighbours given separately: out[i] = mid[i] | (prev & next) with
+// prev = i ? mid[i-1] : before, next = i < n-1 ? mid[i+1] : after.  A Z-slab rank closes the ORIGINAL halo slices it got
+// from a neighbour itself (slab.py): one exchange of originals instead of one for the stencil's neighbours and a second one
+// for the closed halo.  `out` must not overlap `mid`.
+__global__ __launch_bounds__(256) void close_stencil_kernel(const u64 *__restrict__ before, const u64 *__restrict__ mid,
+                                                            const u64 *__restrict__ after, int n, int64_t slice_words,
+                                                            u64 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * slice_words) return;
+    const int z = (int)(i / slice_words);
+    const int64_t w = i - (int64_t)z * slice_words;
+    const u64 prev = z ? mid[i - slice_words] : before[w];
+    const u64 next = z < n - 1 ? mid[i + slice_words] : after[w];
+    out[i] = mid[i] | (prev & next);
+}
+
+TOMO_API int tomo_close_stencil(const uint64_t *before, const uint64_t *mid, const uint64_t *after, int n, int ny, int nx,
+                                uint64_t *out, void *stream)
+{
+    if (!before || !mid || !after || !out || n < 1 || ny <= 0 || nx <= 0) return TOMO_E_ARG;
+    const int64_t slice_words = (int64_t)ny * tomo_words_per_row(nx);
+    hipLaunchKernelGGL(close_stencil_kernel, dim3((unsigned)ceil_div64((int64_t)n * slice_words, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const u64 *)before, (const u64 *)mid, (const u64 *)after, n, slice_words, (u64 *)out);
+    return tomo_status();
+}
+
 // The fused pass for ONE Z-slab of a sharded stack (slab.py): mask = the slab's nz slices, bits = its bit volume.
 // lo_fixed / hi_fixed: the slab's first / last slice is a GLOBAL end slice, already packed and filled in `bits` (kept);
 // otherwise the neighbour slice `below` / `above` (bit-packed (ny, wx), ORIGINAL content, from the rank below / above) closes

@@ -34,6 +34,8 @@ import torch
 from . import pipeline
 
 HALO_BITS = 10   # 8 morphology passes + 2 slices for the 5-tap Gaussian along z
+PC_EDGE = 32     # slices at either end of a slab that wait for the neighbours' slices (the rest is packed + closed first)
+SPLIT_PACK = os.environ.get("TOMO_SLAB_SPLIT", "1") not in ("", "0")              # middle of the slab before the neighbour chain (A/B switch)
 DEFERRED_NUMBERING = os.environ.get("TOMO_SLAB_DEFERRED", "1") not in ("", "0")   # the pass with ONE download (A/B switch)
 
 
@@ -61,7 +63,7 @@ class TorchDistComm:
     def _bytes(t):
         return t.reshape(-1) if t.dtype == torch.uint8 else t.view(torch.uint8).reshape(-1)
 
-    def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
+    def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None, defer=False):
         """Neighbour exchange along z.  `to_prev` goes to rank-1, `to_next` to rank+1; a direction is either used
         by EVERY rank (all pass a tensor; the end ranks' tensor simply has no destination) or by none (all pass
         None).  Returns (from_prev, from_next), None where there is no such neighbour / direction.
@@ -93,6 +95,7 @@ class TorchDistComm:
                 from_next = torch.empty(shape, dtype=dtype, device=self.device)
                 if from_next.numel():
                     ops.append(td.P2POp(td.irecv, self._bytes(from_next), r + 1))
+        works = []
         if ops and self.stage_host:
             staged = []
             hops = []
@@ -106,12 +109,27 @@ class TorchDistComm:
                 if op.op is td.irecv:
                     op.tensor.copy_(h)
         elif ops:
-            for q in td.batch_isend_irecv(ops):
-                q.wait()
+            works = td.batch_isend_irecv(ops)
+            if not defer:
+                for q in works:
+                    q.wait()
         self.stats["bytes_sent"] += sum(k.numel() * k.element_size() for k in keep)
         self.stats["calls"] += 1
         self.stats["seconds"] += time.perf_counter() - t_in
-        return from_prev, from_next
+        if not defer:
+            return from_prev, from_next
+
+        def finish(works=works, keep=keep):
+            t0 = time.perf_counter()
+            for q in works:
+                q.wait()
+            self.stats["seconds"] += time.perf_counter() - t0
+        return from_prev, from_next, finish
+
+    def exchange_async(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
+        """exchange() that does not make the current stream wait: -> (from_prev, from_next, finish).  What is enqueued
+        between this call and finish() runs next to the transfer; the received tensors may be used only after finish()."""
+        return self.exchange(to_prev, to_next, dtype, recv_shape_prev, recv_shape_next, defer=True)
 
     def all_gather(self, t):
         import time
@@ -193,6 +211,9 @@ class ThreadComm:
         from_next = self.recv(r + 1, dtype) if (r + 1 < w and to_prev is not None) else None
         return from_prev, from_next
 
+    def exchange_async(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
+        return self.exchange(to_prev, to_next, dtype, recv_shape_prev, recv_shape_next) + ((lambda: None),)
+
     def all_gather(self, t):
         self.slots[self.rank] = self._publish(t)
         self.barrier.wait()
@@ -227,10 +248,14 @@ class HipEngine:
         buf = torch.empty((nzl + 2 * room, ny, wx), dtype=torch.int64, device=mask.device)
         return buf, pipeline.pack(mask, out=buf[room:room + nzl])
 
-    def pack_closed_slab(self, mask, room, comm, first, last):
+    def pack_closed_slab(self, mask, room, comm, first, last, halo=None, merged=False):
         """np.stack + _close_volume_ends for this rank's slices in ONE pass over its mask (pipeline.pack_closed's slab form):
         the first and last slice are packed alone (and filled where they are global end slices), their ORIGINAL content goes
         to the neighbours, and the fused kernel packs everything else with the neighbours' slices closing the stencil.
+        The middle of the slab depends on the mask alone and is enqueued FIRST: the GPU streams through it while the host
+        is busy with the first RCCL call of the pass (after the download that ended the previous pass the host has no lead:
+        the neighbour chain in front cost ~0.2 ms of idle GPU per pass); the PC_EDGE slices at either end follow once the
+        neighbours' slices are there, then (halo = (H, Hu)) the closed halo slices are exchanged into the buffer.
         -> (halo buffer (nzl + 2 room, ny, words), bits of the closed slab = its middle), or None if the layout needs the
         separate kernels (nx % 16 != 0, fewer than 2 slices)."""
         from . import _lib
@@ -238,21 +263,72 @@ class HipEngine:
         nzl, ny, nx = mask.shape
         if nzl < 2 or nx % 16 != 0 or mask.data_ptr() % 16 != 0 or not pipeline.PACK_CLOSE_FUSED:
             return None
+        E = PC_EDGE
+        split = nzl >= 4 * E and SPLIT_PACK
         st = torch.cuda.current_stream().cuda_stream
         wx = L.tomo_words_per_row(nx)
         buf = torch.empty((nzl + 2 * room, ny, wx), dtype=torch.int64, device=mask.device)
         own = buf[room:room + nzl]
+        scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=mask.device)
+        lo_f, hi_f = (1 if first else 0), (1 if last else 0)
+
+        def close_range(z_from, z_to, pb=None, pa=None):
+            _lib.check(L.tomo_pack_close_range(mask.data_ptr(), own.data_ptr(), nzl, ny, nx, z_from, z_to, pb, pa, lo_f, hi_f, st),
+                       "tomo_pack_close_range")
+
+        if merged and halo is not None:
+            # ONE exchange per pass in front of the smoothing: the ORIGINAL edge slices go out (Hu + 1 down, H + 1 up) while
+            # the middle of the slab streams -- its first part covers the host's time in the RCCL call, the rest the
+            # transfer -- and every rank closes its neighbours' halo slices itself (the stencil needs one slice more on
+            # either side: the reason for the + 1) instead of receiving them closed in a second exchange.
+            H, Hu = halo
+            assert room >= Hu >= H and E >= Hu + 1 and nzl >= 4 * E
+            zc = (E + (nzl - 2 * E) * 3 // 4) // 4 * 4        # 3/4 before the RCCL call (its host side takes ~0.15 ms), 1/4 after
+            close_range(E, zc)
+            edge_lo = torch.empty((Hu + 1, ny, wx), dtype=torch.int64, device=mask.device)
+            edge_hi = torch.empty((H + 1, ny, wx), dtype=torch.int64, device=mask.device)
+            _lib.check(L.tomo_pack_bits(mask.data_ptr(), edge_lo.data_ptr(), Hu + 1, ny, nx, st), "tomo_pack_bits")
+            _lib.check(L.tomo_pack_bits(mask[nzl - (H + 1):].data_ptr(), edge_hi.data_ptr(), H + 1, ny, nx, st), "tomo_pack_bits")
+            if first:
+                own[0].copy_(edge_lo[0])
+                _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, 0, scratch.data_ptr(), st), "tomo_fill_holes_slice")
+            if last:
+                own[nzl - 1].copy_(edge_hi[H])
+                _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, nzl - 1, scratch.data_ptr(), st), "tomo_fill_holes_slice")
+            from_prev, from_next, finish = comm.exchange_async(edge_lo, edge_hi, torch.int64)
+            close_range(zc, nzl - E)
+            finish()
+            close_range(0, E, None if first else from_prev[H].data_ptr(), None if last else from_next[0].data_ptr())
+            close_range(nzl - E, nzl, None if first else from_prev[H].data_ptr(), None if last else from_next[0].data_ptr())
+            if not first:      # closed slices z0 - H .. z0 - 1 from the originals z0 - H - 1 .. z0 - 1 and this rank's own z0
+                _lib.check(L.tomo_close_stencil(from_prev[0].data_ptr(), from_prev[1:].data_ptr(), edge_lo[0].data_ptr(), H, ny, nx,
+                                                buf[room - H:room].data_ptr(), st), "tomo_close_stencil")
+            if not last:       # closed slices z1 .. z1 + Hu - 1 from this rank's own z1 - 1 and the originals z1 .. z1 + Hu
+                _lib.check(L.tomo_close_stencil(edge_hi[H].data_ptr(), from_next[:Hu].data_ptr(), from_next[Hu].data_ptr(), Hu, ny, nx,
+                                                buf[room + nzl:room + nzl + Hu].data_ptr(), st), "tomo_close_stencil")
+            return buf, own
+        if split:
+            close_range(E, nzl - E)
         for z in (0, nzl - 1):
             _lib.check(L.tomo_pack_bits(mask[z].data_ptr(), own[z].data_ptr(), 1, ny, nx, st), "tomo_pack_bits")
-        scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=mask.device)
         if first:
             _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, 0, scratch.data_ptr(), st), "tomo_fill_holes_slice")
         if last:
             _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, nzl - 1, scratch.data_ptr(), st), "tomo_fill_holes_slice")
         below, above = comm.exchange(own[:1], own[nzl - 1:], torch.int64)
-        _lib.check(L.tomo_pack_close_slab(mask.data_ptr(), own.data_ptr(), nzl, ny, nx,
-                                          None if below is None else below.data_ptr(), None if above is None else above.data_ptr(),
-                                          1 if first else 0, 1 if last else 0, st), "tomo_pack_close_slab")
+        pb = None if below is None else below.data_ptr()
+        pa = None if above is None else above.data_ptr()
+        for z_from, z_to in (((0, E), (nzl - E, nzl)) if split else ((0, nzl),)):
+            _lib.check(L.tomo_pack_close_range(mask.data_ptr(), own.data_ptr(), nzl, ny, nx, z_from, z_to, pb, pa, lo_f, hi_f, st),
+                       "tomo_pack_close_range")
+        if halo is not None:
+            H, Hu = halo
+            assert room >= Hu >= H
+            lo, hi = comm.exchange(own[:Hu], own[nzl - H:], torch.int64)
+            if not first:
+                buf[room - H:room].copy_(lo)
+            if not last:
+                buf[room + nzl:room + nzl + Hu].copy_(hi)
         return buf, own
 
     def bits(self, vol):
@@ -468,10 +544,15 @@ class SlabJob:
         Hu = H + 1          # one more slice from above: the field slice marching cubes needs beyond the slab is computed HERE
         buf = None
         fused = None
+        halo_done = False
         if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
-            fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last)
+            # one exchange of ORIGINAL edge slices instead of two (stencil neighbours, then closed halos): a joint decision,
+            # so it goes by the thinnest slab of the job, not by this rank's
+            merged = SPLIT_PACK and self.gz // self.world >= 4 * PC_EDGE and PC_EDGE >= Hu + 1 and hasattr(c, "exchange_async")
+            fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last, (H, Hu), merged)
         if fused is not None:
-            buf, bits = fused                               # packed and closed in one pass over the mask
+            buf, bits = fused                               # packed and closed in one pass over the mask, halos in place
+            halo_done = True
         else:
             if self.world > 1 and hasattr(e, "pack_into"):
                 buf, vol = e.pack_into(mask, Hu)            # the slab in the middle of its halo-extended buffer
@@ -481,12 +562,14 @@ class SlabJob:
         closed = e.from_bits(bits, (nzl, self.ny, self.nx))
         # halo for morphology + Gaussian: H closed slices from below, H + 1 from above
         if self.world > 1:
-            lo, hi = c.exchange(bits[:Hu], bits[nzl - H:], torch.int64)
+            if not halo_done:
+                lo, hi = c.exchange(bits[:Hu], bits[nzl - H:], torch.int64)
             if buf is not None:                             # room is Hu on either side: the lower halo leaves one slice unused
-                if not first:
-                    buf[Hu - H:Hu].copy_(lo)
-                if not last:
-                    buf[Hu + nzl:].copy_(hi)
+                if not halo_done:
+                    if not first:
+                        buf[Hu - H:Hu].copy_(lo)
+                    if not last:
+                        buf[Hu + nzl:].copy_(hi)
                 a0, b0 = (Hu if first else Hu - H), Hu + nzl + (0 if last else Hu)
                 ext = e.from_bits(buf[a0:b0], (b0 - a0, self.ny, self.nx))
             else:

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Per-rank cost of a Z-slab pass WITH RCCL in the loop, on a one-GPU box.
+
+RCCL refuses two ranks on one device, so this is a rehearsal, not a measurement of a multi-GPU run: ONE process plays a
+middle rank (rank 1 of a pretend world of 3) and every message it would send to a neighbour goes to ITSELF through a
+real world-size-1 `nccl` process group -- the same batched isend / irecv of uint8 views and the same all-gather the job
+uses, enqueued on the same streams.  What arrives "from below" is what was sent "up" (and vice versa), so the halo
+content is not that of a real stack (the mesh has a seam and is not checked); sizes, kernels, launches, host round trips
+and the RCCL calls are those of a middle rank.  What is missing is the time on the xGMI link (3 MB per pass).
+usage: slab_selfloop_bench.py [slices_per_rank] [ny] [nx] [steps]"""
+import datetime
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomography_3d_reconstructor_amd import pipeline, slab  # noqa: E402
+
+
+class SelfLoopComm(slab.TorchDistComm):
+    def __init__(self, device, rank=1, world=3):
+        super().__init__(device)
+        self.rank, self.world = rank, world
+
+    def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None, defer=False):
+        t_in = time.perf_counter()
+        ops, keep = [], []
+        from_prev = from_next = None
+        for send, shape in ((to_next, recv_shape_prev), (to_prev, recv_shape_next)):
+            if send is None:
+                continue
+            got = torch.empty(tuple(shape) if shape is not None else tuple(send.shape), dtype=dtype, device=self.device)
+            if send is to_next:
+                from_prev = got
+            else:
+                from_next = got
+            if send.numel() and got.numel():
+                assert send.numel() * send.element_size() == got.numel() * got.element_size(), "self loop: sizes differ"
+                keep.append(send.contiguous())
+                ops.append(td.P2POp(td.isend, self._bytes(keep[-1]), 0))
+                ops.append(td.P2POp(td.irecv, self._bytes(got), 0))
+        works = td.batch_isend_irecv(ops) if ops else []
+        if not defer:
+            for q in works:
+                q.wait()
+        self.stats["bytes_sent"] += sum(k.numel() * k.element_size() for k in keep)
+        self.stats["calls"] += 1
+        self.stats["seconds"] += time.perf_counter() - t_in
+        if not defer:
+            return from_prev, from_next
+        return from_prev, from_next, (lambda works=works, keep=keep: [q.wait() for q in works])
+
+    def all_gather(self, t):
+        t_in = time.perf_counter()
+        out = [torch.empty_like(t)]
+        td.all_gather(out, t.contiguous())
+        self.stats["bytes_sent"] += t.numel() * t.element_size()
+        self.stats["calls"] += 1
+        self.stats["seconds"] += time.perf_counter() - t_in
+        return out * self.world
+
+
+def main():
+    nzr = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    ny = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    nx = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29618")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    comm = SelfLoopComm(dev)
+    gz = 3 * nzr
+    job = slab.SlabJob(gz, ny, nx, comm)
+    mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
+    depths = np.full(gz, 1.0)
+    res = None
+    for _ in range(4):
+        res = job.run(mask, depths, 1.0, 1.0)
+    comm.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host = 0.0
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        res = job.run(mask, depths, 1.0, 1.0)
+        host += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    slab_ms = (time.perf_counter() - t0) / steps * 1e3
+    st = comm.stats
+    nv, nf = int(res[0].shape[0]), int(res[1].shape[0])
+    del res
+    # the single-GPU pass on a stack of the slab's size, same box
+    m1 = pipeline.ellipsoid_mask(nzr, ny, nx, dev).view(torch.uint8)
+    d1 = np.full(nzr, 1.0)
+    for it in range(steps + 3):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(m1), 3, True), d1, 1.0, 1.0)
+    torch.cuda.synchronize()
+    one_ms = (time.perf_counter() - t0) / steps * 1e3
+    print("middle rank of %d x (%d, %d, %d), messages to self over a 1-rank nccl group: %.3f ms per pass "
+          "(%d deferred, %d redone; %.1f RCCL calls and %.0f KB sent per pass, %.3f ms of host time inside them, "
+          "%.3f ms of host time per pass in run()); %d vertices, %d faces kept; single-GPU pass on a slab-sized ellipsoid "
+          "stack: %.3f ms" % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
+                              st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms),
+          flush=True)
+    td.barrier()
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
