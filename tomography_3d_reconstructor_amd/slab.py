@@ -4,11 +4,12 @@ The reference is single-process; this is the scale-out of the SAME path (SURVEY.
 cut along z, rank r owns slices [z0, z1).  Only small, fixed exchanges happen, all with the z-neighbours
 (RCCL send/recv over xGMI) plus one tiny all-gather (the vertex counts):
 
-  close ends   c'[z] = c[z] | (c[z+1] & c'[z-1]) is the local stencil c[z] | (c[z-1] & c[z+1]): one ORIGINAL slice
-               from either neighbour (one two-way exchange of one bit-packed slice), no carry from further away.
-  smoothing    8 passes of a radius-1 stencil + 2 slices for the Gaussian: one exchange of 10 (from below) / 11 (from
-               above) bit-packed halo slices, after which every pass runs locally (the contaminated rim shrinks
-               into the halo).
+  close ends   c'[z] = c[z] | (c[z+1] & c'[z-1]) is the local stencil c[z] | (c[z-1] & c[z+1]): a slab needs ORIGINAL slices
+  + smoothing  of its neighbours only.  ONE exchange of bit-packed original edge slices (11 up, 12 down) while the middle
+               of the slab is packed + closed; every rank closes its neighbours' halo slices itself: 10 below / 11 above
+               (8 passes of a radius-1 stencil + 2 for the Gaussian + 1 for the field slice beyond the slab), after which
+               every smoothing pass runs locally (the contaminated rim shrinks into the halo).  Slabs thinner than 128
+               slices: two exchanges (the stencil's neighbour slices, then the closed halos).
   field        computed locally on the halo-extended slab; the owned field slices are exact.
   marching     needs field slice z1 of rank r+1: computed locally from one more bit-packed halo slice from above
   cubes        (11 instead of 10; no float data travels).
