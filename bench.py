@@ -62,6 +62,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1; gloo (halos staged through the host) only to rehearse the "
                          "multi-rank code path with several ranks on ONE GPU -- never a measurement")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="with --gpus 1: run the N > 1 code path (process group, RCCL communicator, preflight, Z-slab job, comm "
+                         "statistics) with ONE rank -- a check of the plumbing on a one-GPU box, never a measurement")
     ap.add_argument("--sparse-field", action="store_true",
                     help="opt-in: do not materialise the parts of the float field that marching cubes cannot read "
                          "(same mesh; NOT the headline configuration -- the roofline entry then only carries a note)")
@@ -245,7 +248,10 @@ def run(args, world):
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or args.rehearse_dist
+    if args.rehearse_dist and world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(args.master_port or _free_port())), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
     if args.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)        # rehearsal: ranks may share a GPU
     if not torch.cuda.is_available() or local >= torch.cuda.device_count():
@@ -272,7 +278,25 @@ def run(args, world):
     job = comm = None
     if dist:
         from tomography_3d_reconstructor_amd import slab
-        comm = slab.TorchDistComm(dev)
+        comm = None
+        if args.backend == "nccl" and os.environ.get("TOMO_RCCL_DIRECT", "1") not in ("", "0"):
+            # RCCL through its C API on the compute stream (rccl.py): no cross-stream joins, ~0.2 ms less per pass than the
+            # process group's calls in the one-GPU rehearsal.  Creating the communicator is collective, so the ranks first
+            # agree (all-reduce over the process group) that everybody could load the library.
+            from tomography_3d_reconstructor_amd import rccl
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                rccl.lib()
+            except Exception as e:                     # noqa: BLE001
+                print("bench.py: rank %d: librccl not usable directly (%r)" % (rank, e), file=sys.stderr, flush=True)
+                ok.zero_()
+            td.all_reduce(ok, op=td.ReduceOp.MIN)
+            if int(ok.item()):
+                comm = rccl.RcclComm(dev)
+            elif rank == 0:
+                print("bench.py: falling back to torch.distributed collectives", file=sys.stderr, flush=True)
+        if comm is None:
+            comm = slab.TorchDistComm(dev)
         try:
             comm_info = slab.preflight(comm)           # one neighbour exchange + one all-gather; who is on which device
         except Exception as e:                         # noqa: BLE001 -- any transport failure: say so and stop, do not hang
@@ -287,9 +311,10 @@ def run(args, world):
 
         def step():
             return job.run(mask, depths, 1.0, 1.0)
-        parallelism = "zslab%d" % world + ("" if args.backend == "nccl" else " (REHEARSAL over gloo, not a measurement)")
+        parallelism = "zslab%d" % world + ("" if args.backend == "nccl" else " (REHEARSAL over gloo, not a measurement)") + (
+            " (REHEARSAL of the multi-rank plumbing with one rank)" if world == 1 else "")
         workload = "%dx%dx%d ellipsoid stack, %d Z-slabs of %d slices (halos over %s)" % (
-            nx, ny, gz, world, job.z1 - job.z0, "RCCL" if args.backend == "nccl" else "gloo")
+            nx, ny, gz, world, job.z1 - job.z0, ("RCCL" + (" C API, compute stream" if hasattr(comm, "close") else "")) if args.backend == "nccl" else "gloo")
     else:
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev).view(torch.uint8)
         depths = np.full(gz, 1.0)
@@ -423,6 +448,8 @@ def run(args, world):
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
     if dist:
+        if hasattr(comm, "close"):
+            comm.close()
         td.destroy_process_group()
 
 

@@ -1,0 +1,49 @@
+"""GPU tier: what of the RCCL transport can run on ONE GPU -- a world-size-1 `nccl` process group and, next to it, the
+communicator the bench uses (rccl.RcclComm: RCCL's C API on the compute stream) with a rank that is its own neighbour.
+Runs tools/rccl_selfloop.py in a child process (a process group is per process; pytest keeps none).  The exchange between
+DISTINCT ranks needs a multi-GPU node and is not covered here."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_self_loop_process_group_and_direct_communicator():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selfloop.py")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-3000:]
+    assert "self-loop batch_isend_irecv on uint8 views: ok" in out
+    assert "RcclComm (C API, compute stream): self-loop exchange, all-gather and a 1-rank SlabJob ok" in out
+    assert "rccl selfloop ok" in out
+
+
+def test_bench_multi_rank_plumbing_with_one_rank():
+    """bench.py --rehearse-dist: process group, the direct RCCL communicator (agreed by all-reduce), preflight, SlabJob,
+    comm statistics and the teardown, with ONE rank -- the code a multi-GPU run goes through before its first exchange."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-dist", "--size", "160", "128", "192", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["comm"]["backend"] == "rccl-direct" and d["comm"]["ranks"] == 1
+    assert d["config"]["n_vertices"] > 0 and d["config"]["n_faces"] > 0 and "REHEARSAL" in d["config"]["parallelism"]
+    # and with the process group's own collectives
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", TOMO_RCCL_DIRECT="0"))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d2 = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert d2["comm"]["backend"] == "nccl"
+    assert (d2["config"]["n_vertices"], d2["config"]["n_faces"]) == (d["config"]["n_vertices"], d["config"]["n_faces"])

@@ -178,7 +178,7 @@ def preflight(comm):
         raise RuntimeError("preflight: all_gather returned ranks %r" % ([row[0] for row in rows],))
     devices = [tuple(row[1:]) for row in rows]
     return {"ranks": w, "distinct_devices": len(set(devices)), "devices": [d[0] for d in devices],
-            "backend": comm.td.get_backend() if hasattr(comm, "td") else "threads"}
+            "backend": getattr(comm, "backend", None) or (comm.td.get_backend() if hasattr(comm, "td") else "threads")}
 
 
 class ThreadComm:

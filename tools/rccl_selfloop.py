@@ -38,6 +38,41 @@ v, fc = job.run(mask, np.full(nz, 1.0), 1.0, 1.0)
 v1, f1 = pipeline.extract_surface(pipeline.smooth(pipeline.close_ends(pipeline.pack(mask)), 3, True), np.full(nz, 1.0), 1.0, 1.0)
 assert torch.equal(v, v1) and torch.equal(fc, f1)
 print("SlabJob over a 1-rank nccl group == single-GPU path: %d vertices, %d faces" % (v.shape[0], fc.shape[0]), flush=True)
+# the same through RCCL's C API on the compute stream (rccl.RcclComm, what bench.py uses over nccl): a rank that plays the
+# middle of three and whose neighbours are itself -- what it sends up must arrive as what comes from below, and vice versa
+from tomography_3d_reconstructor_amd import rccl  # noqa: E402
+
+
+class Loop(rccl.RcclComm):
+    def _peer(self, r):
+        return 0
+
+
+direct = Loop(dev)
+assert (direct.rank, direct.world) == (0, 1)
+print("preflight (direct):", slab.preflight(direct), flush=True)
+direct.rank, direct.world = 1, 3
+up = torch.arange(3 * 1024 * 16, dtype=torch.int64, device=dev).reshape(3, 1024, 16)
+down = -torch.arange(5 * 1024 * 16, dtype=torch.int64, device=dev).reshape(5, 1024, 16)
+from_prev, from_next = direct.exchange(down, up, torch.int64)
+assert torch.equal(from_prev, up) and torch.equal(from_next, down), "self loop over ncclSend / ncclRecv"
+rows = torch.rand((77, 3), device=dev)
+got, none = direct.exchange(None, rows, torch.float32, recv_shape_prev=(77, 3))
+assert none is None and torch.equal(got, rows)
+none, ids = direct.exchange(torch.arange(9, dtype=torch.int32, device=dev), None, torch.int32, recv_shape_next=(9,))
+assert none is None and torch.equal(ids, torch.arange(9, dtype=torch.int32, device=dev))
+a2, b2, fin = direct.exchange_async(down, up, torch.int64)
+fin()
+assert torch.equal(a2, up) and torch.equal(b2, down)
+direct.rank, direct.world = 0, 1
+g = direct.all_gather(torch.tensor([5, 6, 7], dtype=torch.int64, device=dev))
+assert len(g) == 1 and g[0].tolist() == [5, 6, 7]
+job = slab.SlabJob(nz, ny, nx, direct)
+v2, f2 = job.run(mask, np.full(nz, 1.0), 1.0, 1.0)
+assert torch.equal(v2, v1) and torch.equal(f2, f1)
+print("RcclComm (C API, compute stream): self-loop exchange, all-gather and a 1-rank SlabJob ok; calls %d, bytes %d"
+      % (direct.stats["calls"], direct.stats["bytes_sent"]), flush=True)
+direct.close()
 td.barrier()
 td.destroy_process_group()
 print("rccl selfloop ok")

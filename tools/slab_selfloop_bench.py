@@ -64,6 +64,26 @@ class SelfLoopComm(slab.TorchDistComm):
         return out * self.world
 
 
+class SelfLoopRccl:
+    """The same play on rccl.RcclComm (RCCL's C API on the compute stream): logical rank 1 of 3, every peer is rank 0 of the
+    1-rank communicator."""
+
+    def __new__(cls, device):
+        from tomography_3d_reconstructor_amd import rccl
+
+        class _Loop(rccl.RcclComm):
+            def _peer(self, r):
+                return 0
+
+            def all_gather(self, t):
+                return [rccl.RcclComm.all_gather(self, t)[0]] * self.world
+
+        c = _Loop(device)
+        c._real_world = c.world
+        c.rank, c.world = 1, 3
+        return c
+
+
 def main():
     nzr = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     ny = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -74,7 +94,8 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     td.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
-    comm = SelfLoopComm(dev)
+    direct = os.environ.get("TOMO_RCCL_DIRECT", "1") not in ("", "0")
+    comm = SelfLoopRccl(dev) if direct else SelfLoopComm(dev)
     gz = 3 * nzr
     job = slab.SlabJob(gz, ny, nx, comm)
     mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
@@ -105,12 +126,15 @@ def main():
         pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(m1), 3, True), d1, 1.0, 1.0)
     torch.cuda.synchronize()
     one_ms = (time.perf_counter() - t0) / steps * 1e3
-    print("middle rank of %d x (%d, %d, %d), messages to self over a 1-rank nccl group: %.3f ms per pass "
-          "(%d deferred, %d redone; %.1f RCCL calls and %.0f KB sent per pass, %.3f ms of host time inside them, "
-          "%.3f ms of host time per pass in run()); %d vertices, %d faces kept; single-GPU pass on a slab-sized ellipsoid "
-          "stack: %.3f ms" % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
-                              st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms),
+    how = "RCCL communicator (C API, compute stream)" if direct else "nccl group (torch.distributed)"
+    print(("middle rank of %d x (%d, %d, %d), messages to self over a 1-rank " + how + ": %.3f ms per pass "
+           "(%d deferred, %d redone; %.1f RCCL calls and %.0f KB sent per pass, %.3f ms of host time inside them, "
+           "%.3f ms of host time per pass in run()); %d vertices, %d faces kept; single-GPU pass on a slab-sized ellipsoid "
+           "stack: %.3f ms") % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
+                                st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms),
           flush=True)
+    if hasattr(comm, "close"):
+        comm.close()
     td.barrier()
     td.destroy_process_group()
 
