@@ -240,3 +240,38 @@ def test_merged_edge_exchange_matches_single_gpu(dev, world, nz):
         assert np.array_equal(c[0], ref_counts[0]) and np.array_equal(c[1], ref_counts[1])
     if pipeline.MC3 and pipeline.NA_HINTS and slab.DEFERRED_NUMBERING:
         assert stats == [(1, 0)] * world, stats
+
+
+def test_merged_front_with_a_misaligned_mask_on_one_rank(dev):
+    """The one-exchange front is decided jointly; a rank whose mask sits at an odd address (a view) copies it instead of
+    falling back to a path that exchanges differently."""
+    world, nz, ny, nx = 2, 264, 24, 48
+    v = blob(nz, ny, nx, 1.0, 11)
+    depths = np.full(nz, 1.0)
+    ref = single_gpu(v, depths, 1.0, 1.0, dev)
+    out, errs = [None] * world, []
+
+    def target(c):
+        try:
+            job = slab.SlabJob(nz, ny, nx, c)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                part = np.ascontiguousarray(v[job.z0:job.z1]).view(np.uint8)
+                if c.rank == 1:                                   # 3 bytes into a larger buffer: not 16-byte aligned
+                    flat = torch.zeros(part.size + 64, dtype=torch.uint8, device=dev)
+                    mask = flat[3:3 + part.size].view(part.shape)
+                    mask.copy_(torch.from_numpy(part).to(dev))
+                    assert mask.data_ptr() % 16 != 0
+                else:
+                    mask = torch.from_numpy(part).to(dev)
+                verts, faces = job.run(mask, depths, 1.0, 1.0)
+                torch.cuda.current_stream().synchronize()
+            out[c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.vertex_offset, job.n_vertices_global)
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            raise
+
+    ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    check_pass(out, ref)

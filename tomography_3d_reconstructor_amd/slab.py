@@ -262,6 +262,10 @@ class HipEngine:
         from . import _lib
         L = _lib.lib()
         nzl, ny, nx = mask.shape
+        mask = mask.contiguous()
+        if merged and mask.data_ptr() % 16 != 0:
+            mask = mask.clone()     # the one-exchange front is a JOINT decision: a rank must not drop out of it over the address
+            #                         of its own mask (the other paths exchange differently)
         if nzl < 2 or nx % 16 != 0 or mask.data_ptr() % 16 != 0 or not pipeline.PACK_CLOSE_FUSED:
             return None
         E = PC_EDGE
@@ -549,7 +553,8 @@ class SlabJob:
         if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
             # one exchange of ORIGINAL edge slices instead of two (stencil neighbours, then closed halos): a joint decision,
             # so it goes by the thinnest slab of the job, not by this rank's
-            merged = SPLIT_PACK and self.gz // self.world >= 4 * PC_EDGE and PC_EDGE >= Hu + 1 and hasattr(c, "exchange_async")
+            merged = (SPLIT_PACK and self.gz // self.world >= 4 * PC_EDGE and PC_EDGE >= Hu + 1 and hasattr(c, "exchange_async")
+                      and self.nx % 16 == 0 and pipeline.PACK_CLOSE_FUSED)
             fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last, (H, Hu), merged)
         if fused is not None:
             buf, bits = fused                               # packed and closed in one pass over the mask, halos in place
