@@ -659,22 +659,27 @@ __global__ __launch_bounds__(256) void slab_table_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ ids_next, int64_t cap_top,
                                                          int32_t *__restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // four entries per thread (the table has four slots per list position and is 16-byte aligned)
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
     int64_t off_me = 0;
     for (int r = 0; r < rank; ++r) off_me += gathered[8 * r];
     const int64_t off_next = off_me + gathered[8 * rank];
     const bool ok = slab_counts_ok(tot, cap_v);
     const int64_t nv = ok ? (int64_t)tot[1] : 0, k = nv - (ok ? (int64_t)tot[7] : 0);
-    int64_t row = table[i];                   // entries that belong to no vertex hold whatever was in memory
-    row = row < 0 ? 0 : (row >= nv ? (nv > 0 ? nv - 1 : 0) : row);
-    int64_t g;
-    if (row < k) g = row + off_me;
-    else {
+    auto map = [&](int32_t t) -> int32_t {
+        int64_t row = t;                      // entries that belong to no vertex hold whatever was in memory
+        row = row < 0 ? 0 : (row >= nv ? (nv > 0 ? nv - 1 : 0) : row);
+        if (row < k) return (int32_t)(row + off_me);
         const int64_t j = row - k;
-        g = off_next + ((ids_next && j < cap_top) ? (int64_t)ids_next[j] : 0);
+        return (int32_t)(off_next + ((ids_next && j < cap_top) ? (int64_t)ids_next[j] : 0));
+    };
+    if (i4 + 4 <= n && ((((uintptr_t)table) | ((uintptr_t)out)) & 15) == 0) {
+        const int4 t = *(const int4 *)(table + i4);
+        *(int4 *)(out + i4) = make_int4(map(t.x), map(t.y), map(t.z), map(t.w));
+    } else {
+        for (int64_t i = i4; i < n && i < i4 + 4; ++i) out[i] = map(table[i]);
     }
-    out[i] = (int32_t)g;
 }
 
 TOMO_API int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream)
@@ -707,7 +712,7 @@ TOMO_API int tomo_slab_table(const int32_t *table, int64_t n, const unsigned lon
                              int rank, int world, const int32_t *ids_next, int64_t cap_top, int32_t *out, void *stream)
 {
     if (!table || !tot || !gathered || !out || n < 1 || cap_v < 1 || rank < 0 || rank >= world) return TOMO_E_ARG;
-    hipLaunchKernelGGL(slab_table_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, table, n,
+    hipLaunchKernelGGL(slab_table_kernel, dim3((unsigned)ceil_div64(ceil_div64(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, table, n,
                        (const u64 *)tot, cap_v, gathered, rank, ids_next, cap_top, out);
     return tomo_status();
 }
