@@ -158,7 +158,7 @@ TOMO_API int tomo_pack_bits(const uint8_t *mask, uint64_t *bits, int nz, int ny,
 __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
                                                          int nx, int wx, int groups, int runs, int za, int zb, int lo_fixed,
                                                          int hi_fixed, const u64 *__restrict__ below,
-                                                         const u64 *__restrict__ above)
+                                                         const u64 *__restrict__ above, int zr)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
     const int y = (int)(rem / groups), g = (int)(rem - (int64_t)y * groups);
     const int x = g * 1024 + lane * 16, word = g * 16 + (lane >> 2);
     const bool inx = x < nx, inw = word < wx;
-    const int z0 = za + r * PC_ZR, z1 = (z0 + PC_ZR < zb) ? z0 + PC_ZR : zb;                 // outputs z0 .. z1-1
+    const int z0 = za + r * zr, z1 = (z0 + zr < zb) ? z0 + zr : zb;                          // outputs z0 .. z1-1
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const int64_t slice_bytes = (int64_t)ny * nx, slice_words = (int64_t)ny * wx;
     const uint8_t *mp = mask + (int64_t)y * nx + x;
@@ -732,7 +732,7 @@ TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, i
     const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs, 1, nz - 1, 1, 1, (const u64 *)nullptr, (const u64 *)nullptr);
+                       groups, runs, 1, nz - 1, 1, 1, (const u64 *)nullptr, (const u64 *)nullptr, PC_ZR);
     return tomo_status();
 }
 
@@ -751,11 +751,13 @@ TOMO_API int tomo_pack_close_range(const uint8_t *mask, uint64_t *bits, int nz, 
     if ((za == 0 && !below) || (zb == nz && !above)) return TOMO_E_ARG;
     const int wx = (int)tomo_words_per_row(nx);
     const int groups = (wx + 15) / 16;
-    const int runs = (zb - za + PC_ZR - 1) / PC_ZR;
+    // a short range (the 32 slices at an end of a slab) in runs of 8: four times the waves, a quarter of the serial march each
+    const int zr = (zb - za) <= 2 * PC_ZR ? PC_ZR / 4 : PC_ZR;
+    const int runs = (zb - za + zr - 1) / zr;
     const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above);
+                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above, zr);
     return tomo_status();
 }
 
@@ -804,7 +806,7 @@ TOMO_API int tomo_pack_close_slab(const uint8_t *mask, uint64_t *bits, int nz, i
     const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above);
+                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above, PC_ZR);
     return tomo_status();
 }
 
