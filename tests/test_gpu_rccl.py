@@ -47,3 +47,28 @@ def test_bench_multi_rank_plumbing_with_one_rank():
     d2 = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
     assert d2["comm"]["backend"] == "nccl"
     assert (d2["config"]["n_vertices"], d2["config"]["n_faces"]) == (d["config"]["n_vertices"], d["config"]["n_faces"])
+
+
+def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
+    """bench.py --gpus 2 --backend gloo: two rank PROCESSES sharing this GPU, halos staged through the host -- the whole
+    multi-rank code path of the bench (self-launch, process group, TorchDistComm, preflight, one-exchange front, deferred
+    numbering) except the transport; the mesh they report must have the size of the single-GPU mesh of the same stack."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import numpy as np
+    from tomography_3d_reconstructor_amd import pipeline
+    nzr, ny, nx = 160, 96, 128
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", str(nzr), str(ny), str(nx),
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["comm"]["ranks"] == 2 and d["comm"]["backend"] == "gloo"
+    assert d["comm"]["numbering"]["deferred_passes"] >= 3 and d["comm"]["numbering"]["redone"] == 0
+    assert d["comm"]["comm_calls_per_pass_per_rank"] == 4.0
+    dev = torch.device("cuda:0")
+    mask = pipeline.ellipsoid_mask(2 * nzr, ny, nx, dev).view(torch.uint8)
+    v, f = pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(2 * nzr, 1.0), 1.0, 1.0)
+    assert (d["config"]["n_vertices"], d["config"]["n_faces"]) == (v.shape[0], f.shape[0])
