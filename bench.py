@@ -252,6 +252,13 @@ def run(args, world):
     if args.rehearse_dist and world == 1:
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(args.master_port or _free_port())), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
+    json_fd = None
+    if dist:
+        # RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line there.
+        # Everything any library writes to fd 1 from here on goes to stderr; the JSON line is written to the saved fd.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if args.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)        # rehearsal: ranks may share a GPU
     if not torch.cuda.is_available() or local >= torch.cuda.device_count():
@@ -446,7 +453,11 @@ def run(args, world):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-        print(json.dumps(out), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
     if dist:
         if hasattr(comm, "close"):
             comm.close()

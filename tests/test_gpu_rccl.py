@@ -16,7 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_rccl_self_loop_process_group_and_direct_communicator():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selfloop.py")], env=env, capture_output=True, text=True,
                        timeout=300)
     out = p.stdout + p.stderr
@@ -36,8 +41,9 @@ def test_bench_multi_rank_plumbing_with_one_rank():
            "--warmup", "1", "--no-cpu-baseline"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-    line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout: RCCL's banner and the like go to stderr
+    d = json.loads(lines[0])
     assert d["comm"]["backend"] == "rccl-direct" and d["comm"]["ranks"] == 1
     assert d["config"]["n_vertices"] > 0 and d["config"]["n_faces"] > 0 and "REHEARSAL" in d["config"]["parallelism"]
     # and with the process group's own collectives
