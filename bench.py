@@ -299,15 +299,37 @@ def run(args, world):
                 ok.zero_()
             td.all_reduce(ok, op=td.ReduceOp.MIN)
             if int(ok.item()):
-                comm = rccl.RcclComm(dev)
-            elif rank == 0:
+                try:
+                    comm = rccl.RcclComm(dev)
+                except Exception as e:                 # noqa: BLE001
+                    print("bench.py: rank %d: RCCL communicator not created (%r)" % (rank, e), file=sys.stderr, flush=True)
+                    ok.zero_()
+                td.all_reduce(ok, op=td.ReduceOp.MIN)  # everybody or nobody
+                if not int(ok.item()) and comm is not None:
+                    comm.close()
+                    comm = None
+            if comm is None and rank == 0:
                 print("bench.py: falling back to torch.distributed collectives", file=sys.stderr, flush=True)
         if comm is None:
             comm = slab.TorchDistComm(dev)
-        try:
-            comm_info = slab.preflight(comm)           # one neighbour exchange + one all-gather; who is on which device
-        except Exception as e:                         # noqa: BLE001 -- any transport failure: say so and stop, do not hang
-            print("bench.py: rank %d: RCCL preflight failed: %r" % (rank, e), file=sys.stderr, flush=True)
+        comm_info = None
+        for attempt in range(2):
+            # one neighbour exchange + one all-gather, content-checked; who is on which device.  A failure on ANY rank (the
+            # verdicts are all-reduced over the process group) sends everybody from the direct communicator to the process
+            # group's collectives once; a second failure ends the run with a message instead of a hang.
+            good = torch.ones(1, dtype=torch.int32, device=rdev)
+            try:
+                comm_info = slab.preflight(comm)
+            except Exception as e:                     # noqa: BLE001
+                print("bench.py: rank %d: preflight over %s failed: %r" % (rank, type(comm).__name__, e), file=sys.stderr, flush=True)
+                good.zero_()
+            td.all_reduce(good, op=td.ReduceOp.MIN)
+            if int(good.item()):
+                break
+            if attempt == 0 and hasattr(comm, "close"):
+                comm.close()
+                comm = slab.TorchDistComm(dev)
+                continue
             sys.exit(3)
         if args.backend == "nccl" and comm_info["distinct_devices"] != world:
             print("bench.py: %d ranks on %d distinct devices" % (world, comm_info["distinct_devices"]), file=sys.stderr)
