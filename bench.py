@@ -35,6 +35,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -276,6 +277,17 @@ def run(args, world):
         else:
             td.init_process_group("gloo", timeout=tmo)
     rdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the small reductions of this script live
+    beat = [time.monotonic()]
+    if dist:
+        # RCCL's C API has no timeout of its own (the process group's watchdog only covers its collectives): a rank that
+        # makes no progress for two minutes -- communicator, preflight, a pass -- says so and leaves instead of hanging the node
+        def watchdog():
+            while True:
+                time.sleep(5.0)
+                if time.monotonic() - beat[0] > 120.0:
+                    print("bench.py: rank %d: no progress for 120 s -- giving up" % rank, file=sys.stderr, flush=True)
+                    os._exit(4)
+        threading.Thread(target=watchdog, daemon=True).start()
 
     (gz, ny, nx), scaling, wname = workload_shape(args, world)
     timer = FieldTimer(torch, _lib.lib())
@@ -334,6 +346,7 @@ def run(args, world):
         if args.backend == "nccl" and comm_info["distinct_devices"] != world:
             print("bench.py: %d ranks on %d distinct devices" % (world, comm_info["distinct_devices"]), file=sys.stderr)
             sys.exit(3)
+        beat[0] = time.monotonic()
         job = slab.SlabJob(gz, ny, nx, comm)
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
         depths = np.full(gz, 1.0)
@@ -362,6 +375,13 @@ def run(args, world):
             td.barrier()
             torch.cuda.synchronize()
 
+    if dist:
+        plain_step = step
+
+        def step():
+            out = plain_step()
+            beat[0] = time.monotonic()
+            return out
     res = None
     for _ in range(2):          # allocator priming (untimed, like the warm-up): the first passes grow torch's memory pool
         res = step()
