@@ -308,16 +308,20 @@ int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t 
  *   tomo_slab_summary   out int64[8] = kept rows | missing | flags (1 chain overflow, 2 rows not strictly ascending,
  *                       4 n_top > cap_top, 8 caller_flags != 0) | rows | top rows | rows announced from below | list length |
  *                       triangles -- what the ranks all-gather
- *   tomo_slab_table     out[i] = GLOBAL index of the row table[i] names: own rows by position + this rank's offset (the
- *                       sum of the lower ranks' kept rows in `gathered`, int64[world][8]), top-plane rows through ids_next
- *                       (what the upper rank's tomo_slab_lookup found) + the upper rank's offset */
+ *   tomo_mc3_faces_slab tomo_mc3_faces with GLOBAL indices: row r of this rank's list (what `table` names) leaves as r + this
+ *                       rank's offset (the sum of the lower ranks' kept rows in `gathered`, int64[world][8]) while r < kept
+ *                       rows, and as ids_next[r - kept] (what the upper rank's tomo_slab_lookup found) + the upper rank's
+ *                       offset for the rows on the shared top plane */
 int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream);
 int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
                      int32_t *out, unsigned long long *missing, void *stream);
 int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, const unsigned long long *missing,
                       int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream);
-int tomo_slab_table(const int32_t *table, int64_t n, const unsigned long long *tot, int64_t cap_v, const int64_t *gathered,
-                    int rank, int world, const int32_t *ids_next, int64_t cap_top, int32_t *out, void *stream);
+int tomo_mc3_faces_slab(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
+                        const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,
+                        const uint16_t *vox_used, const uint32_t *blk3, const int32_t *table, int64_t *faces, int64_t cap_f,
+                        const int64_t *gathered, int rank, int world, const int32_t *ids_next, int64_t cap_top, int64_t cap_v,
+                        void *stream);
 int tomo_mesh_faces(const int32_t *faces32, int64_t nf, const int32_t *rank, int64_t *faces_out,
                     unsigned long long *totals, void *workspace, int64_t workspace_bytes, void *stream);
 /* Speculative one-pass variant: faces_out[f] = rank[faces32[f]] for every face (int64), totals[1] = nf, and totals[3]

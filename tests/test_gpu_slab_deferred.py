@@ -146,7 +146,8 @@ def test_deferred_pass_with_coinciding_rows(dev):
 
 
 def test_slab_kernels_take_counts_from_device_memory(dev):
-    """tomo_slab_top_rows / lookup / summary / table on hand-made inputs against NumPy."""
+    """tomo_slab_top_rows / lookup / summary on hand-made inputs against NumPy (the mapping to global indices inside the triangle
+    kernel is covered by every deferred pass of this file)."""
     e = slab.HipEngine()
     rng = np.random.default_rng(4)
     nv, nt, cap_v, cap = 500, 37, 640, 64
@@ -181,19 +182,6 @@ def test_slab_kernels_take_counts_from_device_memory(dev):
     assert int(e.slab_summary(tot_small, cap_v, None, None, cap, 0)[2].item()) == 2           # rows not strictly ascending
     tot_small[3] = 1
     assert int(e.slab_summary(tot_small, cap_v, None, None, cap, 0)[2].item()) & 1            # a chain buffer overflowed
-    # table of global indices: own rows by position + offset, top rows through the upper rank's answer
-    gathered = torch.tensor([[1000, 0, 0, 0, 0, 0, 0, 0], [nv - nt, 0, 0, nv, nt, 0, 0, 0], [nu2, 0, 0, 0, 0, 0, 0, 0]],
-                            dtype=torch.int64, device=dev)
-    table = torch.from_numpy(rng.integers(0, nv, 2000).astype(np.int32)).to(dev)
-    table[7], table[9] = -5, 2 ** 31 - 1                                  # entries of no vertex: anything, clamped
-    ids_next = torch.from_numpy(want.astype(np.int32)).to(dev)
-    ids_pad = torch.zeros(cap, dtype=torch.int32, device=dev)
-    ids_pad[:nt] = ids_next
-    got = e.slab_table(table, 2000, tot, cap_v, gathered, 1, 3, ids_pad, cap).cpu().numpy()
-    t = np.clip(table.cpu().numpy().astype(np.int64), 0, nv - 1)
-    k = nv - nt
-    exp = np.where(t < k, t + 1000, want[np.clip(t - k, 0, nt - 1)] + 1000 + k)
-    assert np.array_equal(got, exp.astype(np.int32))
 
 
 @pytest.mark.parametrize("world,nz", [(2, 300), (3, 391)])

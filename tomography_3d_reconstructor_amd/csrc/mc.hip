@@ -1139,13 +1139,19 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_vertices_kernel(const McGrid g, c
 // LDS and leave as coalesced 8-byte stores (three scattered 8-byte stores per triangle cost 4x the bytes in partial-line
 // writes: 730 MB of WRITE_SIZE for 170 MB of triangles at 1024^3), in windows of MC3_FWIN triangles.
 #define MC3_FWIN 1024
+// SLAB: the triangles of a Z-slab rank leave with GLOBAL vertex indices (slab.py, the pass without host round trips): row r of
+// this rank's list is r + the sum of the lower ranks' kept rows while r < k = rows - rows on the shared top plane, and
+// ids_next[r - k] + the upper rank's offset for the shared rows (what the upper rank's tomo_slab_lookup found); every count
+// comes from device memory (tot, the all-gathered summaries) and the mapping is applied where the staged indices leave LDS.
+struct Mc3SlabMap { const int64_t *gathered; const int32_t *ids_next; int64_t cap_top, cap_v; int rank; };
+template <bool SLAB>
 __global__ __launch_bounds__(MC3_BLK) void mc3_faces_kernel(const McGrid g, const u64 *__restrict__ vox_key, int64_t cap,
                                                             u64 *__restrict__ tot, const u64 *__restrict__ seg_act,
                                                             const u32 *__restrict__ seg_aoff, const u32 *__restrict__ vox_loc,
                                                             const int32_t *__restrict__ vox_til, const uint16_t *__restrict__ vox_used,
                                                             const u32 *__restrict__ blk3, int64_t nblk,
                                                             const int32_t *__restrict__ table, int64_t *__restrict__ faces,
-                                                            int64_t cap_f)
+                                                            int64_t cap_f, const Mc3SlabMap sm)
 {
     __shared__ int32_t sf[3 * MC3_FWIN];
     const int64_t i = (int64_t)blockIdx.x * MC3_BLK + threadIdx.x;
@@ -1243,7 +1249,20 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_faces_kernel(const McGrid g, cons
         __syncthreads();
         const u32 n = 3u * (total - w0 < MC3_FWIN ? total - w0 : (u32)MC3_FWIN);
         int64_t *dst = faces + 3 * (int64_t)(fbase + w0);
-        for (u32 e = threadIdx.x; e < n; e += MC3_BLK) dst[e] = (int64_t)sf[e];
+        if constexpr (SLAB) {
+            int64_t off_me = 0;
+            for (int r = 0; r < sm.rank; ++r) off_me += sm.gathered[8 * r];
+            const int64_t off_next = off_me + sm.gathered[8 * sm.rank];
+            const bool ok = tot[1] <= (u64)sm.cap_v && tot[7] <= tot[1];
+            const int64_t k = ok ? (int64_t)(tot[1] - tot[7]) : 0;
+            for (u32 e = threadIdx.x; e < n; e += MC3_BLK) {
+                const int64_t row = (int64_t)sf[e];
+                const int64_t j = row - k;
+                dst[e] = row < k ? row + off_me : off_next + ((sm.ids_next && j < sm.cap_top) ? (int64_t)sm.ids_next[j] : 0);
+            }
+        } else {
+            for (u32 e = threadIdx.x; e < n; e += MC3_BLK) dst[e] = (int64_t)sf[e];
+        }
         __syncthreads();
     }
     if (degen) atomicAdd((unsigned long long *)&tot[5], (unsigned long long)degen);
@@ -1311,7 +1330,26 @@ TOMO_API int tomo_mc3_faces(int Nz, int Ny, int Nx, int xorg, const unsigned lon
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
     const int64_t nblk = ceil_div64(cap, MC3_BLK);
-    hipLaunchKernelGGL(mc3_faces_kernel, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, g, (const u64 *)vox_key, cap,
-                       (u64 *)tot, (const u64 *)seg_act, seg_aoff, vox_loc, vox_til, vox_used, blk3, nblk, table, faces, cap_f);
+    hipLaunchKernelGGL(mc3_faces_kernel<false>, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, g, (const u64 *)vox_key, cap,
+                       (u64 *)tot, (const u64 *)seg_act, seg_aoff, vox_loc, vox_til, vox_used, blk3, nblk, table, faces, cap_f,
+                       Mc3SlabMap{nullptr, nullptr, 0, 0, 0});
+    return tomo_status();
+}
+
+TOMO_API int tomo_mc3_faces_slab(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,
+                                 unsigned long long *tot, const unsigned long long *seg_act, const uint32_t *seg_aoff,
+                                 const uint32_t *vox_loc, const int32_t *vox_til, const uint16_t *vox_used, const uint32_t *blk3,
+                                 const int32_t *table, int64_t *faces, int64_t cap_f, const int64_t *gathered, int rank, int world,
+                                 const int32_t *ids_next, int64_t cap_top, int64_t cap_v, void *stream)
+{
+    if (Nz < 2 || Ny < 2 || Nx < 2 || !vox_key || !tot || !seg_act || !seg_aoff || !vox_loc || !vox_til || !vox_used || !blk3 || !table || !faces ||
+        cap <= 0 || cap_f < 0 || !gathered || rank < 0 || rank >= world || cap_v < 1 || cap_top < 0)
+        return TOMO_E_ARG;
+    McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
+    g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
+    const int64_t nblk = ceil_div64(cap, MC3_BLK);
+    hipLaunchKernelGGL(mc3_faces_kernel<true>, dim3((unsigned)nblk), dim3(MC3_BLK), 0, (hipStream_t)stream, g, (const u64 *)vox_key, cap,
+                       (u64 *)tot, (const u64 *)seg_act, seg_aoff, vox_loc, vox_til, vox_used, blk3, nblk, table, faces, cap_f,
+                       Mc3SlabMap{gathered, ids_next, cap_top, cap_v, rank});
     return tomo_status();
 }

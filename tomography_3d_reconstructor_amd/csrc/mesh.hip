@@ -583,7 +583,7 @@ TOMO_API int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query,
 // A Z-slab rank (slab.py) numbers its vertices against its neighbours': the rows on the plane it shares with the rank above
 // close its sorted list (tot[7] of them, counted by uq3_rank_kernel), go up, are looked up there, and their indices come
 // back.  With the message capacities known from the last pass none of the counts has to reach the host before the triangles
-// are written: these four kernels take every count from device memory.
+// are written: these three kernels (and mc3_faces_kernel<true>, which writes the GLOBAL indices) take every count from device memory.
 //   message up   float32 (cap + 1, 3): row 0 = {number of rows as uint32 bits, 0, 0}, then the rows, zero padded
 //   summary      int64[8] per rank, all-gathered: kept rows | rows from below not found | flags | nv | n_top |
 //                rows announced from below | list length | triangles
@@ -654,34 +654,6 @@ __global__ void slab_summary_kernel(const u64 *__restrict__ tot, int64_t cap_v, 
     out[7] = (int64_t)tot[2];
 }
 
-__global__ __launch_bounds__(256) void slab_table_kernel(const int32_t *__restrict__ table, int64_t n, const u64 *__restrict__ tot,
-                                                         int64_t cap_v, const int64_t *__restrict__ gathered, int rank,
-                                                         const int32_t *__restrict__ ids_next, int64_t cap_top,
-                                                         int32_t *__restrict__ out)
-{
-    // four entries per thread (the table has four slots per list position and is 16-byte aligned)
-    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    int64_t off_me = 0;
-    for (int r = 0; r < rank; ++r) off_me += gathered[8 * r];
-    const int64_t off_next = off_me + gathered[8 * rank];
-    const bool ok = slab_counts_ok(tot, cap_v);
-    const int64_t nv = ok ? (int64_t)tot[1] : 0, k = nv - (ok ? (int64_t)tot[7] : 0);
-    auto map = [&](int32_t t) -> int32_t {
-        int64_t row = t;                      // entries that belong to no vertex hold whatever was in memory
-        row = row < 0 ? 0 : (row >= nv ? (nv > 0 ? nv - 1 : 0) : row);
-        if (row < k) return (int32_t)(row + off_me);
-        const int64_t j = row - k;
-        return (int32_t)(off_next + ((ids_next && j < cap_top) ? (int64_t)ids_next[j] : 0));
-    };
-    if (i4 + 4 <= n && ((((uintptr_t)table) | ((uintptr_t)out)) & 15) == 0) {
-        const int4 t = *(const int4 *)(table + i4);
-        *(int4 *)(out + i4) = make_int4(map(t.x), map(t.y), map(t.z), map(t.w));
-    } else {
-        for (int64_t i = i4; i < n && i < i4 + 4; ++i) out[i] = map(table[i]);
-    }
-}
-
 TOMO_API int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream)
 {
     if (!uniq || !tot || !msg || cap < 1 || cap_v < 1) return TOMO_E_ARG;
@@ -705,15 +677,6 @@ TOMO_API int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, con
     if (!tot || !out || cap_v < 1 || cap_top < 0) return TOMO_E_ARG;
     hipLaunchKernelGGL(slab_summary_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const u64 *)tot, cap_v, msg_in,
                        (const u64 *)missing, cap_top, caller_flags, out);
-    return tomo_status();
-}
-
-TOMO_API int tomo_slab_table(const int32_t *table, int64_t n, const unsigned long long *tot, int64_t cap_v, const int64_t *gathered,
-                             int rank, int world, const int32_t *ids_next, int64_t cap_top, int32_t *out, void *stream)
-{
-    if (!table || !tot || !gathered || !out || n < 1 || cap_v < 1 || rank < 0 || rank >= world) return TOMO_E_ARG;
-    hipLaunchKernelGGL(slab_table_kernel, dim3((unsigned)ceil_div64(ceil_div64(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, table, n,
-                       (const u64 *)tot, cap_v, gathered, rank, ids_next, cap_top, out);
     return tomo_status();
 }
 

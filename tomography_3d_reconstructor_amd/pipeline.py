@@ -646,7 +646,9 @@ class Mc3Surface:
         self.nv = self.nf = self.na = 0
         self.deferred = False       # True: enqueued into hint-sized buffers, no count has been read yet (see mc3_vertices)
 
-    def faces(self, table=None, again=False):
+    def faces(self, table=None, again=False, slab_map=None):
+        """slab_map = (gathered int64 (world, 8), rank, world, ids_next int32 or None, cap_top, cap_v): the triangles leave with
+        GLOBAL indices of a Z-slab job, every count taken from device memory (tomo_mc3_faces_slab)."""
         L = _lib.lib()
         f, st = self._f, _stream()
         tab = self.table if table is None else table
@@ -655,6 +657,13 @@ class Mc3Surface:
         if again:
             self._tot[5:7].zero_()                               # the counters of an earlier faces pass
         faces = torch.empty((max(self._cap_f, 1), 3), dtype=torch.int64, device=tab.device)
+        if slab_map is not None:
+            gathered, rank, world, ids_next, cap_top, cap_v = slab_map
+            _lib.check(L.tomo_mc3_faces_slab(f.Nz, f.Ny, f.Nx, f.xorg, _p(self._vox_key), self._cap, _p(self._tot), _p(self._seg_act),
+                                             _p(self._seg_aoff), _p(self._vox_loc), _p(self._vox_til), _p(self._vox_used), _p(self._blk3),
+                                             _p(tab), _p(faces), self._cap_f, _p(gathered), rank, world, _p(ids_next), cap_top, cap_v, st),
+                       "tomo_mc3_faces_slab")
+            return faces
         _lib.check(L.tomo_mc3_faces(f.Nz, f.Ny, f.Nx, f.xorg, _p(self._vox_key), self._cap, _p(self._tot), _p(self._seg_act),
                                     _p(self._seg_aoff), _p(self._vox_loc), _p(self._vox_til), _p(self._vox_used), _p(self._blk3), _p(tab), _p(faces),
                                     self._cap_f, st), "tomo_mc3_faces")

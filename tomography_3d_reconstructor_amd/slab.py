@@ -457,14 +457,6 @@ class HipEngine:
                                                 torch.cuda.current_stream().cuda_stream), "tomo_slab_summary")
         return out
 
-    def slab_table(self, table, n, tot, cap_v, gathered, rank, world, ids_next, cap_top):
-        from . import _lib
-        out = torch.empty(n, dtype=torch.int32, device=table.device)
-        _lib.check(_lib.lib().tomo_slab_table(table.data_ptr(), n, tot.data_ptr(), cap_v, gathered.data_ptr(), rank, world,
-                                              None if ids_next is None else ids_next.data_ptr(), cap_top, out.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "tomo_slab_table")
-        return out
-
     def download(self, t):
         return pipeline._download_vec(t)
 
@@ -601,7 +593,7 @@ class SlabJob:
         dev = mask.device
         if hasattr(e, "mc3_vertices"):
             z_top = None if (last or self.world == 1) else self._z_top(slice_depths, dev)
-            deferred = self._deferred_ok and DEFERRED_NUMBERING and self.world > 1 and hasattr(e, "slab_table")
+            deferred = self._deferred_ok and DEFERRED_NUMBERING and self.world > 1 and hasattr(e, "slab_summary")
             m = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=deferred)
             if m is not NotImplemented:
                 ready = m is not None and hasattr(e, "mc3_ready") and bool(e.mc3_ready(f, Za))
@@ -732,8 +724,9 @@ class SlabJob:
     def _numbering_deferred(self, m, f, Za, slice_depths, mm_y, mm_x, z_top, dev):
         """_global_numbering_mc3 without a host round trip before the triangles are written: the chain ran from size hints
         and has not been read (m.deferred), the shared-plane rows travel in messages of the capacity both neighbours took
-        from the last pass (count in the header row), the lookup, the offsets and the table of GLOBAL indices take every
-        count from device memory, and ONE download at the end brings this rank's counters and every rank's summary.
+        from the last pass (count in the header row), the lookup, the offsets and the triangle kernel (which writes GLOBAL
+        indices) take every count from device memory, and ONE download at the end brings this rank's counters and every
+        rank's summary.
         Anything that did not fit or is not exact -- on ANY rank: the summaries are all-gathered, so all ranks decide alike --
         sends every rank through the exact pass once more.  Every rank issues the same three collective steps whatever its
         own state (a rank whose chain came back resolved or empty flags that in its summary)."""
@@ -758,8 +751,7 @@ class SlabJob:
         _, ids_next = c.exchange(down, None, torch.int32, recv_shape_next=(cap_top,))
         faces = None
         if live:
-            table_g = e.slab_table(m.table, 4 * m._cap, tot, cap_v, gathered, r, w, None if last else ids_next, cap_top)
-            faces = m.faces(table_g)
+            faces = m.faces(slab_map=(gathered, r, w, None if last else ids_next, cap_top, cap_v))
         host = e.download(torch.cat([tot.view(torch.int64).reshape(-1), gathered.reshape(-1)]))
         own, g = host[:8], [host[8 + 8 * i:16 + 8 * i] for i in range(w)]
         bad = any(row[1] or row[2] for row in g) or any(g[i][4] != g[i + 1][5] for i in range(w - 1))
