@@ -30,7 +30,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.environ.get("TOMO_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        L = ctypes.CDLL(path)          # the handle of the copy torch has loaded already (same path)
         vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
         L.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), i, _UniqueId, i]
