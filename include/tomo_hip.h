@@ -304,7 +304,8 @@ int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t 
  * reference): all counts come from `tot` of the rank's mc3 chain (tot[1] rows, tot[7] of them on the shared top plane).
  *   tomo_slab_top_rows  msg float32[(cap + 1) * 3]: row 0 = {n_top as uint32 bits, 0, 0}, then the top-plane rows, zero padded
  *   tomo_slab_lookup    out[i] = index of row i of a received message in this rank's uniq, -1 past its count or when the
- *                       row is not there (then *missing += 1; zeroed by the caller)
+ *                       row is not there (then *missing += 1; zero before the first call -- tomo_slab_summary reads it and
+ *                       clears it again)
  *   tomo_slab_summary   out int64[8] = kept rows | missing | flags (1 chain overflow, 2 rows not strictly ascending,
  *                       4 n_top > cap_top, 8 caller_flags != 0) | rows | top rows | rows announced from below | list length |
  *                       triangles -- what the ranks all-gather
@@ -315,7 +316,7 @@ int tomo_mesh_lookup(const float *uniq, int64_t nu, const float *query, int64_t 
 int tomo_slab_top_rows(const float *uniq, const unsigned long long *tot, int64_t cap_v, int64_t cap, float *msg, void *stream);
 int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
                      int32_t *out, unsigned long long *missing, void *stream);
-int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, const unsigned long long *missing,
+int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, unsigned long long *missing,
                       int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream);
 int tomo_mc3_faces_slab(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
                         const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,

@@ -111,7 +111,7 @@ def run_slab_threads(dev, mask, shape, depths, world, obj_path=None):
                     # once more: the second pass of a job runs without host round trips (one download at its end)
                     first_pass = (verts, faces, job.vertex_offset, job.n_vertices_global)
                     verts, faces = job.run(mask[job.z0:job.z1].view(torch.uint8), depths, 1.0, 1.0)
-                    assert (job.deferred_passes, job.deferred_redone) == (1, 0), (job.deferred_passes, job.deferred_redone)
+                    assert (job.deferred_passes, job.deferred_redone) == (1, 0), (job.deferred_passes, job.deferred_redone, c.rank, repr(job.deferred_why))
                     assert torch.equal(verts, first_pass[0]) and torch.equal(faces, first_pass[1])
                     assert (job.vertex_offset, job.n_vertices_global) == first_pass[2:]
                     del first_pass

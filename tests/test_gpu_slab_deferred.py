@@ -176,6 +176,7 @@ def test_slab_kernels_take_counts_from_device_memory(dev):
     assert list(s) == [nv - nt, 0, 0, nv, nt, 0, 123, 77]
     s2 = e.slab_summary(tot2, nu2 + 50, torch.from_numpy(m2).to(dev), miss, 0, 1).cpu().numpy()
     assert list(s2) == [nu2, 1, 8, nu2, 0, nt, 1, 1]
+    assert int(miss.item()) == 0                                           # read once, cleared for the next pass
     tot_small = tot.clone()
     assert int(e.slab_summary(tot_small, cap_v, None, None, nt - 1, 0)[2].item()) == 4        # message capacity too small
     tot_small[4] = 3

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void slab_lookup_kernel(const float *__restric
 }
 
 __global__ void slab_summary_kernel(const u64 *__restrict__ tot, int64_t cap_v, const float *__restrict__ msg_in,
-                                    const u64 *__restrict__ missing, int64_t cap_top, int64_t caller_flags,
+                                    u64 *__restrict__ missing, int64_t cap_top, int64_t caller_flags,
                                     int64_t *__restrict__ out)
 {
     if (blockIdx.x | threadIdx.x) return;
@@ -646,6 +646,7 @@ __global__ void slab_summary_kernel(const u64 *__restrict__ tot, int64_t cap_v, 
     const int64_t from_prev = msg_in ? (int64_t)__float_as_uint(msg_in[0]) : 0;
     out[0] = (flags & 1) ? 0 : (int64_t)(tot[1] - tot[7]);
     out[1] = missing ? (int64_t)*missing : 0;
+    if (missing) *missing = 0ull;               // read once per pass: cleared here for the next lookup (no memset per pass)
     out[2] = flags;
     out[3] = (int64_t)tot[1];
     out[4] = (int64_t)tot[7];
@@ -671,12 +672,12 @@ TOMO_API int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, 
     return tomo_status();
 }
 
-TOMO_API int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, const unsigned long long *missing,
+TOMO_API int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, unsigned long long *missing,
                                int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream)
 {
     if (!tot || !out || cap_v < 1 || cap_top < 0) return TOMO_E_ARG;
     hipLaunchKernelGGL(slab_summary_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const u64 *)tot, cap_v, msg_in,
-                       (const u64 *)missing, cap_top, caller_flags, out);
+                       (u64 *)missing, cap_top, caller_flags, out);
     return tomo_status();
 }
 

@@ -376,19 +376,21 @@ def marching_cubes(f: Field, level: float = 0.5, z_offset: int = 0):
     return mesh
 
 
-_depth_tables = {}      # (device, add_padding, bytes of the depth table) -> (cum, adj) device tensors
+_depth_tables = {}      # (device, thread, add_padding, bytes of the depth table) -> (cum, adj) device tensors
 
 
 def _depth_tables_on_device(d, add_padding, dev):
     """surface_extractor.py:88-95: adjusted depths and their cumulative sums, uploaded once per distinct table (the
     orchestrator and the benchmark pass the same table call after call)."""
-    key = (str(dev), bool(add_padding), d.tobytes())
+    # per thread: the rank threads of a rehearsed slab job run on their own streams, and a tensor made on one stream must not
+    # be handed to kernels of another without the allocator knowing
+    key = (str(dev), threading.get_ident(), bool(add_padding), d.tobytes())
     hit = _depth_tables.get(key)
     if hit is None:
         adj = np.concatenate([[d[0]], d, [d[-1]]]) if add_padding else d
         cum = np.cumsum(np.concatenate([[0], adj]))
         hit = (torch.from_numpy(np.ascontiguousarray(cum)).to(dev), torch.from_numpy(np.ascontiguousarray(adj)).to(dev))
-        if len(_depth_tables) >= 8:
+        if len(_depth_tables) >= 32:
             _depth_tables.pop(next(iter(_depth_tables)))
         _depth_tables[key] = hit
     return hit

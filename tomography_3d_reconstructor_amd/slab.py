@@ -199,8 +199,17 @@ class ThreadComm:
     def send(self, t, dst):
         self.q[(self.rank, dst)].put(self._publish(t))
 
+    @staticmethod
+    def _adopt(t):
+        """A tensor another thread allocated (on ITS stream) is about to be read by kernels of this thread's stream: tell the
+        caching allocator, or the block goes back to the other stream's pool -- and is handed out and overwritten there --
+        as soon as this thread drops the reference, which in a pass without host round trips is long before its kernels ran."""
+        if t is not None and t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))
+        return t
+
     def recv(self, src, dtype):
-        return self.q[(src, self.rank)].get(timeout=120)
+        return self._adopt(self.q[(src, self.rank)].get(timeout=120))
 
     def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
         r, w = self.rank, self.world
@@ -218,7 +227,7 @@ class ThreadComm:
     def all_gather(self, t):
         self.slots[self.rank] = self._publish(t)
         self.barrier.wait()
-        out = [self.slots[i] for i in range(self.world)]
+        out = [self._adopt(self.slots[i]) for i in range(self.world)]
         self.barrier.wait()
         return out
 
@@ -441,10 +450,12 @@ class HipEngine:
                                                  torch.cuda.current_stream().cuda_stream), "tomo_slab_top_rows")
         return msg
 
-    def slab_lookup(self, uniq, tot, cap_v, msg, cap):
+    def slab_lookup(self, uniq, tot, cap_v, msg, cap, miss=None):
+        """miss: a zeroed int64[1] the caller keeps between passes (slab_summary reads and clears it), or None: a fresh one."""
         from . import _lib
         out = torch.empty(cap, dtype=torch.int32, device=uniq.device)
-        miss = torch.zeros(1, dtype=torch.int64, device=uniq.device)
+        if miss is None:
+            miss = torch.zeros(1, dtype=torch.int64, device=uniq.device)
         _lib.check(_lib.lib().tomo_slab_lookup(uniq.data_ptr(), tot.data_ptr(), cap_v, msg.data_ptr(), cap, out.data_ptr(),
                                                miss.data_ptr(), torch.cuda.current_stream().cuda_stream), "tomo_slab_lookup")
         return out, miss
@@ -495,6 +506,7 @@ class SlabJob:
         self._deferred_ok = False
         self._cap_top = self._cap_prev = 0
         self.deferred_passes = self.deferred_redone = 0
+        self.deferred_why = None
 
     # -- step 1: closed slab (bits tensor of the owned slices)
     def _close_ends(self, vol, buf=None, room=0):
@@ -741,10 +753,11 @@ class SlabJob:
             tot[3] = 1
             uniq, cap_v = torch.zeros((1, 3), dtype=torch.float32, device=dev), 1
         cap_top, cap_prev = (0 if last else self._cap_top), (0 if first else self._cap_prev)
-        token = torch.zeros(3, dtype=torch.float32, device=dev)
-        up = token if last else e.slab_top_rows(uniq, tot, cap_v, cap_top)
+        up = torch.zeros(3, dtype=torch.float32, device=dev) if last else e.slab_top_rows(uniq, tot, cap_v, cap_top)
         from_prev, _ = c.exchange(None, up, torch.float32, recv_shape_prev=((cap_prev + 1) * 3,))
-        idx_prev, miss = (None, None) if first else e.slab_lookup(uniq, tot, cap_v, from_prev, cap_prev)
+        if not first and getattr(self, "_miss", None) is None:
+            self._miss = torch.zeros(1, dtype=torch.int64, device=dev)       # zeroed once: slab_summary clears it after reading
+        idx_prev, miss = (None, None) if first else e.slab_lookup(uniq, tot, cap_v, from_prev, cap_prev, self._miss)
         summary = e.slab_summary(tot, cap_v, None if first else from_prev, miss, cap_top, 0 if live else 1)
         gathered = torch.stack(c.all_gather(summary)).contiguous()
         down = torch.zeros(1, dtype=torch.int32, device=dev) if first else idx_prev
@@ -759,6 +772,8 @@ class SlabJob:
             # rare: a hint or a message capacity was too small, rows that do not ascend strictly (the general sort decides),
             # a row from below that is new here -- everybody takes the exact pass
             self.deferred_redone += 1
+            self.deferred_why = {"summaries": g, "tot": own, "hint": pipeline._MC3_HINT.get(getattr(m, "_hint_key", None)) if m is not None else None,
+                                 "caps": (getattr(m, "_cap", None), getattr(m, "_cap_v", None), getattr(m, "_cap_f", None)) if m is not None else None}
             self._deferred_ok = False
             m2 = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=False)
             ready = m2 is not None and bool(e.mc3_ready(f, Za))
