@@ -72,8 +72,11 @@ def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["comm"]["ranks"] == 2 and d["comm"]["backend"] == "gloo"
-    assert d["comm"]["numbering"]["deferred_passes"] >= 3 and d["comm"]["numbering"]["redone"] == 0
-    assert d["comm"]["comm_calls_per_pass_per_rank"] == 4.0
+    from tomography_3d_reconstructor_amd import slab
+    deferred = slab.DEFERRED_NUMBERING and pipeline.MC3 and pipeline.NA_HINTS            # (A/B switches of the environment)
+    assert d["comm"]["numbering"]["redone"] == 0 and (d["comm"]["numbering"]["deferred_passes"] >= 3) == bool(deferred)
+    if deferred and pipeline.PACK_CLOSE_FUSED:
+        assert d["comm"]["comm_calls_per_pass_per_rank"] == (4.0 if slab.SPLIT_PACK else 5.0)
     dev = torch.device("cuda:0")
     mask = pipeline.ellipsoid_mask(2 * nzr, ny, nx, dev).view(torch.uint8)
     v, f = pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(2 * nzr, 1.0), 1.0, 1.0)
