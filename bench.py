@@ -69,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--sparse-field", action="store_true",
                     help="opt-in: do not materialise the parts of the float field that marching cubes cannot read "
                          "(same mesh; NOT the headline configuration -- the roofline entry then only carries a note)")
+    ap.add_argument("--read-every-pass", action="store_true",
+                    help="A/B: the host reads the counters of a pass before it enqueues the next one (the GPU idles meanwhile)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the cube the CPU oracle is timed on")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of a self-launched run (0: pick a free one)")
     return ap.parse_args(argv)
@@ -158,6 +160,14 @@ def one_pass(mask, depths):
     vol = pipeline.pack_closed(mask)                   # np.stack + _close_volume_ends, one pass over the mask
     vol = pipeline.smooth(vol, 3, True)
     return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
+
+
+def one_pass_submit(mask, depths):
+    """one_pass whose counters have not been read yet: -> an object with .result() (pipeline.extract_surface_submit)."""
+    from tomography_3d_reconstructor_amd import pipeline
+    vol = pipeline.pack_closed(mask)
+    vol = pipeline.smooth(vol, 3, True)
+    return pipeline.extract_surface_submit(vol, depths, 1.0, 1.0, True, True)
 
 
 def cpu_baseline(n):
@@ -351,8 +361,9 @@ def run(args, world):
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
         depths = np.full(gz, 1.0)
 
-        def step():
-            return job.run(mask, depths, 1.0, 1.0)
+        def submit():
+            return job.submit(mask, depths, 1.0, 1.0)
+        collect = job.result
         parallelism = "zslab%d" % world + ("" if args.backend == "nccl" else " (REHEARSAL over gloo, not a measurement)") + (
             " (REHEARSAL of the multi-rank plumbing with one rank)" if world == 1 else "")
         workload = "%dx%dx%d ellipsoid stack, %d Z-slabs of %d slices (halos over %s)" % (
@@ -361,8 +372,11 @@ def run(args, world):
         mask = pipeline.ellipsoid_mask(gz, ny, nx, dev).view(torch.uint8)
         depths = np.full(gz, 1.0)
 
-        def step():
-            return one_pass(mask, depths)
+        def submit():
+            return one_pass_submit(mask, depths)
+
+        def collect(p):
+            return p.result()
         parallelism = "single"
         workload = "%dx%dx%d ellipsoid stack" % (nx, ny, gz)
     if wname in CONFIG_INDEX and (gz, ny, nx) == WORKLOADS[wname]:
@@ -375,25 +389,36 @@ def run(args, world):
             td.barrier()
             torch.cuda.synchronize()
 
-    if dist:
-        plain_step = step
+    def step():
+        out = collect(submit())
+        beat[0] = time.monotonic()
+        return out
 
-        def step():
-            out = plain_step()
+    def steps_in_order(n):
+        """n passes, one after the other on one stream.  The host enqueues pass k + 1 BEFORE it reads the counters of pass k
+        (one small download per pass): the GPU does not idle while the host reads, checks and slices the outputs of the
+        pass before.  Every pass is complete -- results read and checked -- when this returns."""
+        out = pend = None
+        for _ in range(n):
+            nxt = submit()
+            if pend is not None:
+                out = collect(pend)
+            pend = nxt
             beat[0] = time.monotonic()
-            return out
+        if pend is not None:
+            out = collect(pend)
+        return out
     res = None
     for _ in range(2):          # allocator priming (untimed, like the warm-up): the first passes grow torch's memory pool
         res = step()
-    for _ in range(args.warmup):
-        res = step()
+    if args.warmup:
+        res = steps_in_order(args.warmup)
     if comm is not None:
         comm.reset_stats()
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = steps_in_order(args.steps) if not args.read_every_pass else [step() for _ in range(args.steps)][-1]
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -460,6 +485,8 @@ def run(args, world):
         "config": {"workload": workload, "workload_id": wname, "parallelism": parallelism,
                    "inputs": "uint8 mask stack resident in HBM", "outputs": "final (vertices, faces) resident in HBM",
                    "field": "tile-sparse (opt-in)" if pipeline.FIELD_SPARSE else "dense",
+                   "submission": ("host reads every pass before enqueueing the next" if args.read_every_pass else
+                                  "passes strictly one after the other on one stream; the host enqueues pass k+1 before it reads the counters of pass k"),
                    "n_vertices": nverts, "n_faces": nfaces},
         "roofline": roofline,
         "pass_floor": {"bytes": pass_floor_bytes, "frac": round(pass_floor_bytes / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -478,6 +505,14 @@ def run(args, world):
         torch.cuda.synchronize()
         out["cold_pass_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         out["cold_pass_note"] = "one pass with the marching-cubes size hints and path counters cleared (allocator warm)"
+        del r
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(4, min(args.steps, 10))):
+            r = step()
+        torch.cuda.synchronize()
+        out["read_every_pass_ms_per_step"] = round((time.perf_counter() - t0) / max(4, min(args.steps, 10)) * 1e3, 3)
+        out["read_every_pass_note"] = "side measurement: the host reads a pass's counters before it enqueues the next pass (round 1 / 2's `ms_per_step`)"
         del r
         tif = two_in_flight(mask, depths, max(4, min(args.steps, 10)))
         if tif is not None:

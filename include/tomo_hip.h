@@ -89,6 +89,17 @@ int tomo_pack_close_range(const uint8_t *mask, uint64_t *bits, int nz, int ny, i
 /* The stencil on n bit-packed slices whose neighbours are given separately: out[i] = mid[i] | (prev & next), prev = i ?
  * mid[i-1] : before, next = i < n-1 ? mid[i+1] : after ((ny, wx) words per slice; out must not overlap mid).  A Z-slab
  * rank closes the ORIGINAL halo slices of its neighbours with it. */
+/* Launch-count savers of the Z-slab front (slab.py; scale-out of voxel_processor.py:46, :56-77, no counterpart in the
+ * single-process reference): tomo_pack_bits_pair = two tomo_pack_bits in one launch (the original edge slices for the two
+ * neighbours; needs nx % 16 == 0 and 16-byte aligned masks); tomo_slab_edges = tomo_pack_close_range(0, edge) +
+ * tomo_pack_close_range(nz - edge, nz) + the two tomo_close_stencil calls on the neighbours' halo slices (lo_n / hi_n = 0:
+ * no such neighbour) in ONE launch. */
+int tomo_pack_bits_pair(const uint8_t *maskA, uint64_t *bitsA, int nzA, const uint8_t *maskB, uint64_t *bitsB, int nzB,
+                        int ny, int nx, void *stream);
+int tomo_slab_edges(const uint8_t *mask, uint64_t *bits, int nz, int ny, int nx, int edge, const uint64_t *below,
+                    const uint64_t *above, int lo_fixed, int hi_fixed, const uint64_t *lo_before, const uint64_t *lo_mid,
+                    const uint64_t *lo_after, int lo_n, uint64_t *lo_out, const uint64_t *hi_before, const uint64_t *hi_mid,
+                    const uint64_t *hi_after, int hi_n, uint64_t *hi_out, void *stream);
 int tomo_close_stencil(const uint64_t *before, const uint64_t *mid, const uint64_t *after, int n, int ny, int nx,
                        uint64_t *out, void *stream);
 /* The z recurrence of _close_volume_ends (voxel_processor.py:72-75), in place.
@@ -318,6 +329,10 @@ int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t c
                      int32_t *out, unsigned long long *missing, void *stream);
 int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, unsigned long long *missing,
                       int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream);
+/* tomo_slab_lookup + tomo_slab_summary in one single-workgroup launch, without the global `missing` counter (msg == NULL, the
+ * lowest rank: the summary alone). */
+int tomo_slab_lookup_summary(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
+                             int32_t *out, int64_t cap_top, int64_t caller_flags, int64_t *summary, void *stream);
 int tomo_mc3_faces_slab(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
                         const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,
                         const uint16_t *vox_used, const uint32_t *blk3, const int32_t *table, int64_t *faces, int64_t cap_f,

@@ -47,6 +47,9 @@ SIGNATURES = {
     "tomo_fill_holes_ends": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_close_ends": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_close_slab": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p]),
+    "tomo_pack_bits_pair": (_c_i, [_c_p, _c_p, _c_i, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    "tomo_slab_edges": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p,
+                               _c_i, _c_p, _c_p]),
     "tomo_close_stencil": (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     "tomo_pack_close_range": (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p]),
     "tomo_close_ends_workspace_words": (_c_i64, [_c_i, _c_i, _c_i]),
@@ -95,6 +98,7 @@ SIGNATURES = {
     "tomo_slab_top_rows": (_c_i, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tomo_slab_lookup": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "tomo_slab_summary": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tomo_slab_lookup_summary": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tomo_mc3_faces_slab": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                    _c_p, _c_i, _c_i, _c_p, _c_i64, _c_i64, _c_p]),
     "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

@@ -610,6 +610,31 @@ def extract_surface(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x
     return ensure_manifold_mesh(mesh)
 
 
+class PendingSurface:
+    """extract_surface whose counters may not have been read yet: result() -> (vertices, faces) or None."""
+
+    def __init__(self, value=None, surface=None):
+        self._value, self._surface = value, surface
+
+    def result(self):
+        m, self._surface = self._surface, None
+        if m is not None:
+            if m.deferred:
+                m = m.finish()
+            self._value = None if m is None else (m.uniq, m.faces_final)
+        return self._value
+
+
+def extract_surface_submit(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold=True, add_padding=True):
+    """extract_surface in two halves, for a caller that processes one stack after the other: everything is enqueued here
+    (from the size hints of the last surface of this geometry) and the ONE download of the pass is started; .result() waits
+    for it.  Enqueueing the next stack before reading this one keeps the GPU busy through the host's read (bench.py)."""
+    if manifold and MC3:
+        f = make_field(vol, manifold, add_padding, sparse=FIELD_SPARSE)
+        return PendingSurface(surface=mc3_vertices(f, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding, defer=True))
+    return PendingSurface(value=extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding))
+
+
 # ----------------------------------------------------------------------------- mc3: marching cubes + finalise + unique, one chain
 MC3 = os.environ.get("TOMO_MC_PATH", "mc3") != "old"     # manifold=True surfaces through the mc3 chain (csrc/mc.hip, "mc3")
 _MC3_HINT = {}          # field geometry -> (active voxels, vertices, triangles) of the last surface of that geometry
@@ -638,6 +663,29 @@ def _download_vec(t):
     return host.tolist()
 
 
+class PendingDownload:
+    """A small int64 device vector on its way into page-locked memory: started on the current stream, read by wait().
+    Every pending download owns its buffer for as long as it lives (several passes may be in flight), buffers are recycled
+    per (device, thread, length)."""
+    _free = {}
+
+    def __init__(self, t):
+        t = t.reshape(-1)
+        self._key = (str(t.device), threading.get_ident(), int(t.numel()))
+        pool = PendingDownload._free.setdefault(self._key, [])
+        self._host = pool.pop() if pool else torch.empty(t.numel(), dtype=torch.int64, pin_memory=True)
+        self._host.copy_(t, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(t.device))
+
+    def wait(self):
+        self._event.synchronize()
+        out = self._host.tolist()
+        PendingDownload._free[self._key].append(self._host)
+        self._host = None
+        return out
+
+
 class Mc3Surface:
     """Vertices of a surface through the mc3 chain, ready for its triangles: `uniq` (U,3) float32 final rows in np.unique's
     order, `table` int32 (vertex id -> row index; id = 4 * list position of the owner voxel + slot).  faces(table) writes the
@@ -647,6 +695,7 @@ class Mc3Surface:
         self.uniq = self.table = None
         self.nv = self.nf = self.na = 0
         self.deferred = False       # True: enqueued into hint-sized buffers, no count has been read yet (see mc3_vertices)
+        self.finish = None          # deferred WITH faces: finish() reads the counters (one pass late, if the caller likes) -> self | None
 
     def faces(self, table=None, again=False, slab_map=None):
         """slab_map = (gathered int64 (world, 8), rank, world, ids_next int32 or None, cap_top, cap_v): the triangles leave with
@@ -703,13 +752,16 @@ def mc3_hint_ready(f: Field, z_offset=0):
 
 
 def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_padding=True, z_offset=0, with_faces=True,
-                 z_top=None, defer=False):
+                 z_top=None, defer=False, tot=None):
     """surface_extractor.py:55-65 + :82-113 + the vertex half of :115-126 for a manifold=True field at level 0.5.
     -> Mc3Surface (its .faces_final holds the triangles when with_faces), or None where the reference returns None.
     z_top: also count the rows with z' == z_top into tot[7] (a Z-slab rank's plane shared with the rank above).
-    defer (with_faces=False only): when size hints exist, return right after enqueueing -- `.deferred` is set, no count has
-    been read, `_uniq` / `table` have the hinted capacities `_cap_v` / 4 `_cap` and the caller reads `_tot` itself
-    (slab.SlabJob._numbering_deferred); without hints the call behaves as usual."""
+    defer: when size hints exist, return right after enqueueing -- `.deferred` is set, no count has been read.
+    with_faces=False: `_uniq` / `table` have the hinted capacities `_cap_v` / 4 `_cap` and the caller reads `_tot` itself
+    (slab.SlabJob._numbering_deferred; `tot`: where the chain keeps its counters, int64[8]).  with_faces=True: the triangles are enqueued too and the download of the counters has
+    been STARTED; `.finish()` waits for it and completes the call (-> the surface, or None where the reference returns None),
+    so a caller with several stacks to process can enqueue the next pass before it reads this one's counters (bench.py,
+    extract_surface_submit).  Without hints the call behaves as usual (`.deferred` stays False)."""
     L = _lib.lib()
     if min(f.Nz, f.Ny, f.Nx) < 2:
         return None
@@ -726,7 +778,8 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
     _lib.check(L.tomo_mc_classify(_p(f.signs), _p(f.gcls), f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_act), _p(seg_cnt), st), "tomo_mc_classify")
     seg_blk = torch.empty((nseg + 255) // 256, dtype=torch.int32, device=dev)
     seg_aoff = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-    tot = torch.empty(8, dtype=torch.int64, device=dev)
+    if tot is None:                 # the chain's eight counters (a caller may place them inside a larger buffer it downloads)
+        tot = torch.empty(8, dtype=torch.int64, device=dev)
     d = np.ascontiguousarray(slice_depths, dtype=np.float64)
     if len(d):
         cum_t, adj_t = _depth_tables_on_device(d, add_padding, dev)
@@ -777,6 +830,68 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         _lib.check(L.tomo_mc3_sort_rank_top(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, _p(m._slice_tab), _p(tot), _p(m._uniq),
                                             _p(m.table), _p(ws), wsb, z_top, st), "tomo_mc3_sort_rank_top")
 
+    def complete(host, faces):
+        """Everything after the counters of a hinted chain have arrived (host = None: no hinted chain ran)."""
+        if host is not None:
+            if host[3]:
+                COUNTERS["mc3_hint_miss"] = COUNTERS.get("mc3_hint_miss", 0) + 1
+                host = faces = None                              # something did not fit: redo with exact sizes
+            else:
+                COUNTERS["mc3_hint_hit"] = COUNTERS.get("mc3_hint_hit", 0) + 1
+        if host is None:
+            build_list(1 << 16)                                   # a token buffer: tot[0] comes out exact, nothing is written past it
+            na = _download_tot(tot)[0]
+            if na == 0:
+                return None
+            if na >= LIST_LIMIT or na >= 2 ** 29:
+                raise _lib.TomoError("surface too large for 32-bit indices")
+            build_list(na)
+            eval_scan(na, 2 ** 31 - 2, 2 ** 31 - 2)
+            host = _download_tot(tot)
+            nv, nf = host[1], host[2]
+            if nv == 0:
+                _MC3_HINT[hint_key] = (na, 1, 1)
+                return None
+            if nv >= MESH_LIMIT or nf >= MESH_LIMIT:
+                raise _lib.TomoError("mesh too large for 32-bit indices")
+            vertices_sort(na, nv)
+            m._cap_f = max(nf, 1)
+            if with_faces:
+                faces = m.faces()
+            host = _download_tot(tot)
+        m.na, m.nv, m.nf = host[0], host[1], host[2]
+        if m.na == 0 or m.nv == 0:
+            return None
+        if m.na >= LIST_LIMIT:
+            raise _lib.TomoError("surface too large for 32-bit indices")
+        if m.nv >= MESH_LIMIT or m.nf >= MESH_LIMIT:
+            raise _lib.TomoError("mesh too large for 32-bit indices")
+        _MC3_HINT[hint_key] = (m.na, m.nv, m.nf)
+        m.uniq = m._uniq[:m.nv]
+        if host[4]:
+            # duplicate rows or a rounding coincidence: the general sort decides (np.unique semantics), the triangles follow
+            COUNTERS["mc3_general_unique"] = COUNTERS.get("mc3_general_unique", 0) + 1
+            rows = m._vrec[:m.nv, :3].contiguous()
+            uniq, rank = unique_rows(rows)
+            ids = m._vrec[:m.nv, 3].contiguous().view(torch.int32).to(torch.int64)
+            m.table[ids] = rank
+            m.uniq = uniq
+            if with_faces:
+                faces = m.faces(again=True)
+                host = _download_tot(tot)
+        else:
+            COUNTERS["mc3_exact"] = COUNTERS.get("mc3_exact", 0) + 1
+        if with_faces:
+            if host[6]:
+                raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % host[6])
+            faces = faces[:m.nf]
+            if host[5]:                                              # triangles with fewer than three distinct vertices are dropped, order kept
+                COUNTERS["mc3_degenerate"] = COUNTERS.get("mc3_degenerate", 0) + 1
+                keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+                faces = faces[keep]
+            m.faces_final = faces
+        return m
+
     host = None
     faces = None
     if hint:
@@ -793,65 +908,16 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
                 return m
             if with_faces:
                 faces = m.faces()
+            if defer:
+                pend = PendingDownload(tot)
+
+                def finish(pend=pend, faces=faces):
+                    m.deferred, m.finish = False, None
+                    return complete(pend.wait(), faces)
+                m.deferred, m.finish = True, finish
+                return m
             host = _download_tot(tot)
-            if host[3]:
-                COUNTERS["mc3_hint_miss"] = COUNTERS.get("mc3_hint_miss", 0) + 1
-                host = faces = None                              # something did not fit: redo with exact sizes
-            else:
-                COUNTERS["mc3_hint_hit"] = COUNTERS.get("mc3_hint_hit", 0) + 1
-    if host is None:
-        build_list(1 << 16)                                   # a token buffer: tot[0] comes out exact, nothing is written past it
-        na = _download_tot(tot)[0]
-        if na == 0:
-            return None
-        if na >= LIST_LIMIT or na >= 2 ** 29:
-            raise _lib.TomoError("surface too large for 32-bit indices")
-        build_list(na)
-        eval_scan(na, 2 ** 31 - 2, 2 ** 31 - 2)
-        host = _download_tot(tot)
-        nv, nf = host[1], host[2]
-        if nv == 0:
-            _MC3_HINT[hint_key] = (na, 1, 1)
-            return None
-        if nv >= MESH_LIMIT or nf >= MESH_LIMIT:
-            raise _lib.TomoError("mesh too large for 32-bit indices")
-        vertices_sort(na, nv)
-        m._cap_f = max(nf, 1)
-        if with_faces:
-            faces = m.faces()
-        host = _download_tot(tot)
-    m.na, m.nv, m.nf = host[0], host[1], host[2]
-    if m.na == 0 or m.nv == 0:
-        return None
-    if m.na >= LIST_LIMIT:
-        raise _lib.TomoError("surface too large for 32-bit indices")
-    if m.nv >= MESH_LIMIT or m.nf >= MESH_LIMIT:
-        raise _lib.TomoError("mesh too large for 32-bit indices")
-    _MC3_HINT[hint_key] = (m.na, m.nv, m.nf)
-    m.uniq = m._uniq[:m.nv]
-    if host[4]:
-        # duplicate rows or a rounding coincidence: the general sort decides (np.unique semantics), the triangles follow
-        COUNTERS["mc3_general_unique"] = COUNTERS.get("mc3_general_unique", 0) + 1
-        rows = m._vrec[:m.nv, :3].contiguous()
-        uniq, rank = unique_rows(rows)
-        ids = m._vrec[:m.nv, 3].contiguous().view(torch.int32).to(torch.int64)
-        m.table[ids] = rank
-        m.uniq = uniq
-        if with_faces:
-            faces = m.faces(again=True)
-            host = _download_tot(tot)
-    else:
-        COUNTERS["mc3_exact"] = COUNTERS.get("mc3_exact", 0) + 1
-    if with_faces:
-        if host[6]:
-            raise _lib.TomoError("internal error: %d triangle corners reference a missing vertex" % host[6])
-        faces = faces[:m.nf]
-        if host[5]:                                              # triangles with fewer than three distinct vertices are dropped, order kept
-            COUNTERS["mc3_degenerate"] = COUNTERS.get("mc3_degenerate", 0) + 1
-            keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
-            faces = faces[keep]
-        m.faces_final = faces
-    return m
+    return complete(host, faces)
 
 
 def mesh_volume_area(verts: torch.Tensor, faces: torch.Tensor):

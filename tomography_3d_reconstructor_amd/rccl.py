@@ -141,3 +141,15 @@ class RcclComm:
         self.stats["calls"] += 1
         self.stats["seconds"] += time.perf_counter() - t_in
         return list(out.unbind(0))
+
+    def all_gather_into(self, src, out):
+        """out (world, n), contiguous <- every rank's src (n,), on the current stream, no intermediate list / stack."""
+        t_in = time.perf_counter()
+        src = src.contiguous()
+        assert out.is_contiguous() and out.numel() == self.world * src.numel() and out.dtype == src.dtype
+        _check(lib().ncclAllGather(src.data_ptr(), out.data_ptr(), src.numel() * src.element_size(), _UINT8, self._comm,
+                                   self._stream()), "ncclAllGather")
+        self.stats["bytes_sent"] += src.numel() * src.element_size()
+        self.stats["calls"] += 1
+        self.stats["seconds"] += time.perf_counter() - t_in
+        return out

@@ -148,6 +148,16 @@ class TorchDistComm:
         self.stats["seconds"] += time.perf_counter() - t_in
         return out
 
+    def all_gather_into(self, src, out):
+        """out (world, n), contiguous <- every rank's src (n,): the gathered table lands where the caller wants it."""
+        return _gather_into_via_list(self, src, out)
+
+
+def _gather_into_via_list(comm, src, out):
+    """all_gather_into for a communicator that only has all_gather: out (world, n) <- the ranks' src rows."""
+    out.copy_(torch.stack([g.reshape(-1) for g in comm.all_gather(src)]).view_as(out))
+    return out
+
 
 def preflight(comm):
     """First contact of the ranks, before any volume-sized work: ONE neighbour exchange (both directions, the byte-view
@@ -231,6 +241,9 @@ class ThreadComm:
         self.barrier.wait()
         return out
 
+    def all_gather_into(self, src, out):
+        return _gather_into_via_list(self, src, out)
+
     @staticmethod
     def make(world):
         import queue
@@ -301,8 +314,8 @@ class HipEngine:
             close_range(E, zc)
             edge_lo = torch.empty((Hu + 1, ny, wx), dtype=torch.int64, device=mask.device)
             edge_hi = torch.empty((H + 1, ny, wx), dtype=torch.int64, device=mask.device)
-            _lib.check(L.tomo_pack_bits(mask.data_ptr(), edge_lo.data_ptr(), Hu + 1, ny, nx, st), "tomo_pack_bits")
-            _lib.check(L.tomo_pack_bits(mask[nzl - (H + 1):].data_ptr(), edge_hi.data_ptr(), H + 1, ny, nx, st), "tomo_pack_bits")
+            _lib.check(L.tomo_pack_bits_pair(mask.data_ptr(), edge_lo.data_ptr(), Hu + 1, mask[nzl - (H + 1):].data_ptr(), edge_hi.data_ptr(),
+                                             H + 1, ny, nx, st), "tomo_pack_bits_pair")
             if first:
                 own[0].copy_(edge_lo[0])
                 _lib.check(L.tomo_fill_holes_slice(own.data_ptr(), nzl, ny, nx, 0, scratch.data_ptr(), st), "tomo_fill_holes_slice")
@@ -312,14 +325,15 @@ class HipEngine:
             from_prev, from_next, finish = comm.exchange_async(edge_lo, edge_hi, torch.int64)
             close_range(zc, nzl - E)
             finish()
-            close_range(0, E, None if first else from_prev[H].data_ptr(), None if last else from_next[0].data_ptr())
-            close_range(nzl - E, nzl, None if first else from_prev[H].data_ptr(), None if last else from_next[0].data_ptr())
-            if not first:      # closed slices z0 - H .. z0 - 1 from the originals z0 - H - 1 .. z0 - 1 and this rank's own z0
-                _lib.check(L.tomo_close_stencil(from_prev[0].data_ptr(), from_prev[1:].data_ptr(), edge_lo[0].data_ptr(), H, ny, nx,
-                                                buf[room - H:room].data_ptr(), st), "tomo_close_stencil")
-            if not last:       # closed slices z1 .. z1 + Hu - 1 from this rank's own z1 - 1 and the originals z1 .. z1 + Hu
-                _lib.check(L.tomo_close_stencil(edge_hi[H].data_ptr(), from_next[:Hu].data_ptr(), from_next[Hu].data_ptr(), Hu, ny, nx,
-                                                buf[room + nzl:room + nzl + Hu].data_ptr(), st), "tomo_close_stencil")
+            # ONE launch for what is left: the E slices at either end of the slab (they needed the neighbours' slices) and the
+            # stencil on the neighbours' halo slices -- closed slices z0 - H .. z0 - 1 from the originals z0 - H - 1 .. z0 - 1 and
+            # this rank's own z0; closed slices z1 .. z1 + Hu - 1 from this rank's own z1 - 1 and the originals z1 .. z1 + Hu
+            pb, pa = (None if first else from_prev[H].data_ptr()), (None if last else from_next[0].data_ptr())
+            lo = (None, None, None, 0, None) if first else (from_prev[0].data_ptr(), from_prev[1:].data_ptr(), edge_lo[0].data_ptr(), H,
+                                                            buf[room - H:room].data_ptr())
+            hi = (None, None, None, 0, None) if last else (edge_hi[H].data_ptr(), from_next[:Hu].data_ptr(), from_next[Hu].data_ptr(), Hu,
+                                                           buf[room + nzl:room + nzl + Hu].data_ptr())
+            _lib.check(L.tomo_slab_edges(mask.data_ptr(), own.data_ptr(), nzl, ny, nx, E, pb, pa, lo_f, hi_f, *lo, *hi, st), "tomo_slab_edges")
             return buf, own
         if split:
             close_range(E, nzl - E)
@@ -430,14 +444,14 @@ class HipEngine:
     def remap_faces(self, faces32, gid32):
         return pipeline.remap_faces(faces32, gid32)
 
-    def mc3_vertices(self, f, z_offset, depths, mm_y, mm_x, z_top=None, defer=False):
+    def mc3_vertices(self, f, z_offset, depths, mm_y, mm_x, z_top=None, defer=False, tot=None):
         """The production chain (pipeline.mc3_vertices): finalised, sorted, duplicate-free vertex rows of this slab plus
         the table vertex id -> row index; the triangles are written later, through a table of GLOBAL indices.
         z_top: the mapped z of the plane shared with the rank above (its rows are counted on the device); defer: return
         without reading any count when size hints exist (SlabJob._numbering_deferred reads them, once, at the end)."""
         if not pipeline.MC3:
             return NotImplemented
-        return pipeline.mc3_vertices(f, depths, mm_y, mm_x, True, z_offset=z_offset, with_faces=False, z_top=z_top, defer=defer)
+        return pipeline.mc3_vertices(f, depths, mm_y, mm_x, True, z_offset=z_offset, with_faces=False, z_top=z_top, defer=defer, tot=tot)
 
     def mc3_ready(self, f, z_offset):
         return pipeline.mc3_hint_ready(f, z_offset)
@@ -468,8 +482,21 @@ class HipEngine:
                                                 torch.cuda.current_stream().cuda_stream), "tomo_slab_summary")
         return out
 
+    def slab_lookup_summary(self, uniq, tot, cap_v, msg_in, cap, cap_top, caller_flags, summary):
+        """slab_lookup + slab_summary in one launch; `summary` = int64[8] to fill (e.g. this rank's row of the gathered table)."""
+        from . import _lib
+        out = None if msg_in is None else torch.empty(max(cap, 1), dtype=torch.int32, device=uniq.device)
+        _lib.check(_lib.lib().tomo_slab_lookup_summary(uniq.data_ptr(), tot.data_ptr(), cap_v, None if msg_in is None else msg_in.data_ptr(),
+                                                       cap, None if out is None else out.data_ptr(), cap_top, caller_flags,
+                                                       summary.data_ptr(), torch.cuda.current_stream().cuda_stream), "tomo_slab_lookup_summary")
+        return out
+
     def download(self, t):
         return pipeline._download_vec(t)
+
+    def download_start(self, t):
+        """-> an object whose wait() returns the list of ints (the copy runs on the current stream, into its own page-locked buffer)."""
+        return pipeline.PendingDownload(t)
 
     # reductions of the consumers (volume_calculator.py:23-35, 59-94) on the resident bit volume
     def slice_counts(self, vol):
@@ -546,6 +573,27 @@ class SlabJob:
         """mask: this rank's slices (nzl, ny, nx) uint8/bool on the device.  Returns (vertices, faces) of THIS
         rank: its unique vertices (globally sorted across ranks) and its faces with GLOBAL vertex indices, plus
         sets self.vertex_offset / self.n_vertices_global."""
+        return self.result(self.submit(mask, slice_depths, mm_y, mm_x))
+
+    def result(self, ticket):
+        """Second half of run(): waits for the ONE download of a pass that submit() enqueued (a pass that could not run
+        that way was completed inside submit()), checks the summaries of all ranks -- every rank decides alike and repeats
+        the pass the exact way if anything did not fit -- and publishes the pass as the job's current one (mesh, created /
+        smoothed volumes for the consumers below, vertex_offset / n_vertices_global)."""
+        if ticket.get("pending") is not None:
+            ticket["mesh"] = self._numbering_deferred_finish(ticket.pop("pending"))
+            ticket["pending"] = None
+            ticket["numbering"] = (self.vertex_offset, self.n_vertices_global)
+        self.vertex_offset, self.n_vertices_global = ticket["numbering"]
+        self.created, self.smoothed, self.mesh = ticket["created"], ticket["smoothed"], ticket["mesh"]
+        return self.mesh
+
+    def submit(self, mask, slice_depths, mm_y, mm_x):
+        """First half of run(): enqueues the whole pass and returns a ticket for result().  From a job's second pass on
+        (deferred numbering agreed by all ranks) nothing here waits for the GPU, so a caller with a sequence of stacks can
+        submit stack n + 1 BEFORE it asks for the result of stack n: the host's read of the counters then no longer leaves
+        the GPU idle between passes (~0.1 ms per pass in the one-GPU rehearsal).  Every rank must interleave submit() and
+        result() the same way (they issue collective steps)."""
         e, c = self.eng, self.comm
         first, last = self.rank == 0, self.rank == self.world - 1
         nzl = self.z1 - self.z0
@@ -590,7 +638,7 @@ class SlabJob:
         sm = e.smooth(ext, self.iterations, self.create_manifold)
         sb = e.bits(sm)
         own = 0 if (first or self.world == 1) else H
-        self.created, self.smoothed = closed, e.from_bits(sb[own:own + nzl], (nzl, self.ny, self.nx))
+        ticket = {"created": closed, "smoothed": e.from_bits(sb[own:own + nzl], (nzl, self.ny, self.nx)), "mesh": None, "pending": None}
         # the field of slices [z0 - 2, z1 + 3): exact on the owned slices AND on slice z1 -- the first owned slice of the
         # rank above, the one field slice marching cubes reads beyond the slab (round 1 / the first half of round 2 sent it
         # down as a float32 slice: 4 MB per neighbour and an exchange step, against one more bit-packed halo slice)
@@ -605,15 +653,20 @@ class SlabJob:
         dev = mask.device
         if hasattr(e, "mc3_vertices"):
             z_top = None if (last or self.world == 1) else self._z_top(slice_depths, dev)
-            deferred = self._deferred_ok and DEFERRED_NUMBERING and self.world > 1 and hasattr(e, "slab_summary")
-            m = e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=deferred)
+            deferred = self._deferred_ok and DEFERRED_NUMBERING and self.world > 1 and hasattr(e, "slab_lookup_summary")
+            # the counters of a deferred pass live in ONE buffer -- the chain's eight, then every rank's summary -- so that one
+            # copy brings them to the host
+            counters = torch.empty(8 + 8 * self.world, dtype=torch.int64, device=dev) if deferred else None
+            m = (e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=True, tot=counters[:8]) if deferred else
+                 e.mc3_vertices(f, Za, slice_depths, mm_y, mm_x, z_top=z_top, defer=False))
             if m is not NotImplemented:
                 ready = m is not None and hasattr(e, "mc3_ready") and bool(e.mc3_ready(f, Za))
                 if deferred:
-                    self.mesh = self._numbering_deferred(m, f, Za, slice_depths, mm_y, mm_x, z_top, dev)
+                    ticket["pending"] = self._numbering_deferred(m, f, Za, slice_depths, mm_y, mm_x, z_top, dev, counters)
                 else:
-                    self.mesh = self._global_numbering_mc3(m, slice_depths, dev, ready)
-                return self.mesh
+                    ticket["mesh"] = self._global_numbering_mc3(m, slice_depths, dev, ready)
+                    ticket["numbering"] = (self.vertex_offset, self.n_vertices_global)
+                return ticket
         mesh = e.marching_cubes(f, Za)
         vkey = ny = None
         if mesh is None:
@@ -624,8 +677,9 @@ class SlabJob:
             vkey, ny = getattr(mesh, "vkey", None), getattr(mesh, "_ny", None)
             self._mesh_nz = getattr(mesh, "_nz", 0)
             e.finalize_vertices(vpos, slice_depths, mm_y, mm_x)
-        self.mesh = self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
-        return self.mesh
+        ticket["mesh"] = self._global_numbering(vpos, faces32, slice_depths, dev, vkey, ny)
+        ticket["numbering"] = (self.vertex_offset, self.n_vertices_global)
+        return ticket
 
     # -- step 5: vertices on the plane shared with rank+1 belong to rank+1
     def _z_top(self, slice_depths, dev):
@@ -650,6 +704,7 @@ class SlabJob:
         nu0 = nu = uniq.shape[0]
         if self.world == 1:
             self.vertex_offset, self.n_vertices_global = 0, nu
+            self._numbering = None
             return uniq, torch.arange(nu, dtype=torch.int64, device=dev)
         # the rows on the plane shared with rank+1 (mapped z of padded plane z1 + 1, through the same finalisation
         # arithmetic) have the largest z here, so they close the sorted list; they belong to rank+1.  Their number is
@@ -704,6 +759,8 @@ class SlabJob:
         if remap is not None:
             gid = gid[remap]
         assert gid.shape[0] == nu0
+        # for a caller that maps indices on the device (tomo_mc3_faces_slab): the numbers this mapping was made of
+        self._numbering = {"counts": counts, "n_top": n_top, "ids_next": ids_next if n_top else None, "merged": remap is not None}
         return uniq[:k], gid
 
     def _global_numbering(self, vpos, faces32, slice_depths, dev, vkey=None, ny=None):
@@ -729,11 +786,23 @@ class SlabJob:
         kept, gid_rows = self._number_rows(m.uniq, slice_depths, dev, ready)
         if self.n_vertices_global >= 2 ** 31:
             raise pipeline._lib.TomoError("more than 2^31 vertices: the triangle table holds 32-bit indices")
-        # entries of the table that belong to no vertex hold whatever was in memory: clamp before they index anything
+        info = getattr(self, "_numbering", None)
+        if self.world > 1 and info is not None and not info["merged"] and nu == m.nv and getattr(m, "_cap_v", 0) >= m.nv:
+            # the triangle kernel maps this rank's rows to GLOBAL indices itself (own rows by position + the lower ranks' kept
+            # counts, shared-plane rows through the upper rank's answer), as in the pass without round trips; the counts it
+            # takes from `gathered` are the ones the host has just read (was: a table of global indices built with five
+            # elementwise torch kernels over 4 entries per list position, 150 us per rank)
+            g = np.zeros((self.world, 8), dtype=np.int64)
+            g[:, 0] = info["counts"]
+            gathered = torch.from_numpy(g).to(dev)
+            faces = m.faces(again=True, slab_map=(gathered, self.rank, self.world, info["ids_next"], info["n_top"], m._cap_v))
+            return kept, m.faces_checked(faces=faces)
+        # rows merged with the lower rank's (a row from below that was new here) or re-sorted by the general unique: through a
+        # table of global indices; entries that belong to no vertex hold whatever was in memory: clamp before they index anything
         table_g = gid_rows.to(torch.int32)[m.table.clamp_(0, max(nu - 1, 0))]
         return kept, m.faces_checked(table_g, again=True)
 
-    def _numbering_deferred(self, m, f, Za, slice_depths, mm_y, mm_x, z_top, dev):
+    def _numbering_deferred(self, m, f, Za, slice_depths, mm_y, mm_x, z_top, dev, counters):
         """_global_numbering_mc3 without a host round trip before the triangles are written: the chain ran from size hints
         and has not been read (m.deferred), the shared-plane rows travel in messages of the capacity both neighbours took
         from the last pass (count in the header row), the lookup, the offsets and the triangle kernel (which writes GLOBAL
@@ -746,26 +815,35 @@ class SlabJob:
         r, w = self.rank, self.world
         first, last = r == 0, r == w - 1
         live = m is not None and getattr(m, "deferred", False)
+        tot, gathered = counters[:8], counters[8:].view(w, 8)
         if live:
-            tot, uniq, cap_v = m._tot, m._uniq, m._cap_v
+            assert m._tot.data_ptr() == tot.data_ptr()
+            uniq, cap_v = m._uniq, m._cap_v
         else:                                                     # stand-ins: no rows, "overflow" set so that no count is trusted
-            tot = torch.zeros(8, dtype=torch.int64, device=dev)
-            tot[3] = 1
+            tot.copy_(torch.tensor([0, 0, 0, 1, 0, 0, 0, 0], dtype=torch.int64), non_blocking=True)
             uniq, cap_v = torch.zeros((1, 3), dtype=torch.float32, device=dev), 1
         cap_top, cap_prev = (0 if last else self._cap_top), (0 if first else self._cap_prev)
         up = torch.zeros(3, dtype=torch.float32, device=dev) if last else e.slab_top_rows(uniq, tot, cap_v, cap_top)
         from_prev, _ = c.exchange(None, up, torch.float32, recv_shape_prev=((cap_prev + 1) * 3,))
-        if not first and getattr(self, "_miss", None) is None:
-            self._miss = torch.zeros(1, dtype=torch.int64, device=dev)       # zeroed once: slab_summary clears it after reading
-        idx_prev, miss = (None, None) if first else e.slab_lookup(uniq, tot, cap_v, from_prev, cap_prev, self._miss)
-        summary = e.slab_summary(tot, cap_v, None if first else from_prev, miss, cap_top, 0 if live else 1)
-        gathered = torch.stack(c.all_gather(summary)).contiguous()
+        summary = torch.empty(8, dtype=torch.int64, device=dev)
+        idx_prev = e.slab_lookup_summary(uniq, tot, cap_v, None if first else from_prev, cap_prev, cap_top, 0 if live else 1, summary)
+        c.all_gather_into(summary, gathered)
         down = torch.zeros(1, dtype=torch.int32, device=dev) if first else idx_prev
         _, ids_next = c.exchange(down, None, torch.int32, recv_shape_next=(cap_top,))
         faces = None
         if live:
             faces = m.faces(slab_map=(gathered, r, w, None if last else ids_next, cap_top, cap_v))
-        host = e.download(torch.cat([tot.view(torch.int64).reshape(-1), gathered.reshape(-1)]))
+        dl = e.download_start(counters) if hasattr(e, "download_start") else None
+        return {"down": dl, "counters": counters, "m": m, "faces": faces, "f": f, "Za": Za, "depths": slice_depths, "mm": (mm_y, mm_x),
+                "z_top": z_top, "dev": dev}
+
+    def _numbering_deferred_finish(self, t):
+        """The host side of _numbering_deferred: read the counters (possibly one pass late), decide, publish."""
+        e = self.eng
+        r, w = self.rank, self.world
+        m, faces, f, Za, slice_depths, z_top, dev = t["m"], t["faces"], t["f"], t["Za"], t["depths"], t["z_top"], t["dev"]
+        mm_y, mm_x = t["mm"]
+        host = t["down"].wait() if t["down"] is not None else e.download(t["counters"])
         own, g = host[:8], [host[8 + 8 * i:16 + 8 * i] for i in range(w)]
         bad = any(row[1] or row[2] for row in g) or any(g[i][4] != g[i + 1][5] for i in range(w - 1))
         if bad:

@@ -54,6 +54,10 @@ class SelfLoopComm(slab.TorchDistComm):
             return from_prev, from_next
         return from_prev, from_next, (lambda works=works, keep=keep: [q.wait() for q in works])
 
+    def all_gather_into(self, src, out):
+        out.copy_(torch.stack([g.reshape(-1) for g in self.all_gather(src)]).view_as(out))
+        return out
+
     def all_gather(self, t):
         t_in = time.perf_counter()
         out = [torch.empty_like(t)]
@@ -77,6 +81,15 @@ class SelfLoopRccl:
 
             def all_gather(self, t):
                 return [rccl.RcclComm.all_gather(self, t)[0]] * self.world
+
+            def all_gather_into(self, src, out):         # the real 1-rank all-gather fills one row; the pretend neighbours' rows are copies
+                w, self.world = self.world, 1
+                try:
+                    rccl.RcclComm.all_gather_into(self, src, out[:1])
+                finally:
+                    self.world = w
+                out[1:].copy_(out[:1].expand(w - 1, -1))
+                return out
 
         c = _Loop(device)
         c._real_world = c.world
@@ -107,31 +120,80 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host = 0.0
+    serial = os.environ.get("TOMO_READ_EVERY_PASS", "0") not in ("", "0")
+    pend = None
     for _ in range(steps):
         h0 = time.perf_counter()
-        res = job.run(mask, depths, 1.0, 1.0)
+        if serial:
+            res = job.run(mask, depths, 1.0, 1.0)
+        else:                                   # pass k + 1 is enqueued before the host reads the counters of pass k
+            nxt = job.submit(mask, depths, 1.0, 1.0)
+            if pend is not None:
+                res = job.result(pend)
+            pend = nxt
         host += time.perf_counter() - h0
+    if pend is not None:
+        res = job.result(pend)
     torch.cuda.synchronize()
     slab_ms = (time.perf_counter() - t0) / steps * 1e3
-    st = comm.stats
+    st = dict(comm.stats)
     nv, nf = int(res[0].shape[0]), int(res[1].shape[0])
     del res
-    # the single-GPU pass on a stack of the slab's size, same box
-    m1 = pipeline.ellipsoid_mask(nzr, ny, nx, dev).view(torch.uint8)
-    d1 = np.full(nzr, 1.0)
+    # host time of submit() alone: enqueue 4 passes back to back without reading any, then collect them
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    tickets = [job.submit(mask, depths, 1.0, 1.0) for _ in range(4)]
+    enq_ms = (time.perf_counter() - h0) / 4 * 1e3
+    for t in tickets:
+        job.result(t)
+    torch.cuda.synchronize()
+    del tickets
+    # the single-GPU pass on the SAME slices (this rank's own mask stack as a stack of its own: same geometry, same surface
+    # density per slice; its end slices are not empty, so close-ends fills them -- a little more work than the slab's)
+    pend = None
     for it in range(steps + 3):
         if it == 3:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(m1), 3, True), d1, 1.0, 1.0)
+        nxt = pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(nzr, 1.0), 1.0, 1.0)
+        if pend is not None:
+            pend.result()
+        pend = nxt
+    pend.result()
+    torch.cuda.synchronize()
+    same_ms = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    pends = [pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(nzr, 1.0), 1.0, 1.0) for _ in range(4)]
+    enq1_ms = (time.perf_counter() - h0) / 4 * 1e3
+    for q in pends:
+        q.result()
+    del pends, pend, nxt
+    # the single-GPU pass on a stack of the slab's size, same box
+    m1 = pipeline.ellipsoid_mask(nzr, ny, nx, dev).view(torch.uint8)
+    d1 = np.full(nzr, 1.0)
+    pend = None
+    for it in range(steps + 3):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        nxt = pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(m1), 3, True), d1, 1.0, 1.0)
+        if serial:
+            nxt.result()
+        else:
+            if pend is not None:
+                pend.result()
+            pend = nxt
+    if pend is not None:
+        pend.result()
     torch.cuda.synchronize()
     one_ms = (time.perf_counter() - t0) / steps * 1e3
     how = "RCCL communicator (C API, compute stream)" if direct else "nccl group (torch.distributed)"
     print(("middle rank of %d x (%d, %d, %d), messages to self over a 1-rank " + how + ": %.3f ms per pass "
            "(%d deferred, %d redone; %.1f RCCL calls and %.0f KB sent per pass, %.3f ms of host time inside them, "
            "%.3f ms of host time per pass in run()); %d vertices, %d faces kept; single-GPU pass on a slab-sized ellipsoid "
-           "stack: %.3f ms") % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
-                                st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms),
+           "stack: %.3f ms; single-GPU pass on THIS rank's own slices: %.3f ms; host time to enqueue a pass: slab %.3f ms, single %.3f ms") % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
+                                st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms, same_ms, enq_ms, enq1_ms),
           flush=True)
     if hasattr(comm, "close"):
         comm.close()
