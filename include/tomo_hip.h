@@ -329,10 +329,11 @@ int tomo_slab_lookup(const float *uniq, const unsigned long long *tot, int64_t c
                      int32_t *out, unsigned long long *missing, void *stream);
 int tomo_slab_summary(const unsigned long long *tot, int64_t cap_v, const float *msg_in, unsigned long long *missing,
                       int64_t cap_top, int64_t caller_flags, int64_t *out, void *stream);
-/* tomo_slab_lookup + tomo_slab_summary in one single-workgroup launch, without the global `missing` counter (msg == NULL, the
- * lowest rank: the summary alone). */
+/* tomo_slab_lookup + tomo_slab_summary in ONE launch (the workgroup that finishes last writes the summary).  scratch: uint64[2],
+ * zeroed once by the caller, left zero by every call.  msg == NULL (the lowest rank): the summary alone. */
 int tomo_slab_lookup_summary(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
-                             int32_t *out, int64_t cap_top, int64_t caller_flags, int64_t *summary, void *stream);
+                             int32_t *out, int64_t cap_top, int64_t caller_flags, unsigned long long *scratch, int64_t *summary,
+                             void *stream);
 int tomo_mc3_faces_slab(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,
                         const unsigned long long *seg_act, const uint32_t *seg_aoff, const uint32_t *vox_loc, const int32_t *vox_til,
                         const uint16_t *vox_used, const uint32_t *blk3, const int32_t *table, int64_t *faces, int64_t cap_f,

@@ -98,7 +98,7 @@ SIGNATURES = {
     "tomo_slab_top_rows": (_c_i, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tomo_slab_lookup": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "tomo_slab_summary": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
-    "tomo_slab_lookup_summary": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tomo_slab_lookup_summary": (_c_i, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tomo_mc3_faces_slab": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                    _c_p, _c_i, _c_i, _c_p, _c_i64, _c_i64, _c_p]),
     "tomo_mesh_faces": (_c_i, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),

@@ -616,6 +616,7 @@ TOMO_API int tomo_field_fill_bits_sparse(const uint64_t *bits, float *field, int
     hipLaunchKernelGGL(field_worklist_kernel, dim3((unsigned)ceil_div64(blocks, 256)), dim3(256), 0, s, (const unsigned char *)comb,
                        p, list, count);
     p.comb = comb; p.list = list; p.count = count;
+    if (getenv("TOMO_EXP_NEAR_DENSE")) p.comb = nullptr;      // experiment: the listed blocks write ALL their tiles
     hipLaunchKernelGGL(field_tile_kernel<true>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)bits, field, p);
     return tomo_status();
 }

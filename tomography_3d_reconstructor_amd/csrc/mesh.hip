@@ -655,45 +655,55 @@ __global__ void slab_summary_kernel(const u64 *__restrict__ tot, int64_t cap_v, 
     out[7] = (int64_t)tot[2];
 }
 
-// tomo_slab_lookup + tomo_slab_summary in ONE single-workgroup launch (a shared plane holds a few thousand rows: a binary search
-// each, ~20 dependent loads, is latency- not throughput-bound, and the summary needs the number of misses of ALL lookups -- a
-// workgroup barrier instead of a second launch and a global counter).  msg == null (the lowest rank): the summary alone.
-__global__ __launch_bounds__(1024) void slab_lookup_summary_kernel(const float *__restrict__ uniq, const u64 *__restrict__ tot,
-                                                                   int64_t cap_v, const float *__restrict__ msg, int64_t cap,
-                                                                   int32_t *__restrict__ out, int64_t cap_top, int64_t caller_flags,
-                                                                   int64_t *__restrict__ summary)
+// tomo_slab_lookup + tomo_slab_summary in ONE launch: every workgroup looks its share of the received rows up (a binary search
+// each: ~22 dependent loads, so the few thousand rows of a shared plane are spread over many workgroups -- one workgroup alone
+// took 36 us), adds its misses to scratch[1] and takes a ticket from scratch[0]; the workgroup that draws the last ticket sees
+// every miss (fence + atomic), writes the summary and leaves both words zero for the next pass.  scratch: uint64[2], zeroed
+// ONCE by the caller.  msg == null (the lowest rank): the summary alone.
+__global__ __launch_bounds__(256) void slab_lookup_summary_kernel(const float *__restrict__ uniq, const u64 *__restrict__ tot,
+                                                                  int64_t cap_v, const float *__restrict__ msg, int64_t cap,
+                                                                  int32_t *__restrict__ out, int64_t cap_top, int64_t caller_flags,
+                                                                  u64 *__restrict__ scratch, int64_t *__restrict__ summary)
 {
-    __shared__ unsigned long long s_miss;
-    if (threadIdx.x == 0) s_miss = 0ull;
-    __syncthreads();
+    __shared__ int s_last;
+    bool missed = false;
     if (msg != nullptr) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const int64_t nu = slab_counts_ok(tot, cap_v) ? (int64_t)tot[1] : 0;
         const int64_t nq = (int64_t)__float_as_uint(msg[0]);
-        unsigned long long miss = 0;
-        for (int64_t i = threadIdx.x; i < cap; i += blockDim.x) {
-            if (i >= nq) { out[i] = -1; continue; }
-            const float qz = msg[3 + 3 * i], qy = msg[4 + 3 * i], qx = msg[5 + 3 * i];
-            int64_t lo = 0, hi = nu;
-            while (lo < hi) {
-                const int64_t mid = lo + ((hi - lo) >> 1);
-                const float *m = uniq + 3 * mid;
-                const bool less = m[0] < qz || (m[0] == qz && (m[1] < qy || (m[1] == qy && m[2] < qx)));
-                if (less) lo = mid + 1; else hi = mid;
+        if (i < cap) {
+            if (i >= nq) out[i] = -1;
+            else {
+                const float qz = msg[3 + 3 * i], qy = msg[4 + 3 * i], qx = msg[5 + 3 * i];
+                int64_t lo = 0, hi = nu;
+                while (lo < hi) {
+                    const int64_t mid = lo + ((hi - lo) >> 1);
+                    const float *m = uniq + 3 * mid;
+                    const bool less = m[0] < qz || (m[0] == qz && (m[1] < qy || (m[1] == qy && m[2] < qx)));
+                    if (less) lo = mid + 1; else hi = mid;
+                }
+                const bool found = lo < nu && uniq[3 * lo] == qz && uniq[3 * lo + 1] == qy && uniq[3 * lo + 2] == qx;
+                out[i] = found ? (int32_t)lo : -1;
+                missed = !found;
             }
-            const bool found = lo < nu && uniq[3 * lo] == qz && uniq[3 * lo + 1] == qy && uniq[3 * lo + 2] == qx;
-            out[i] = found ? (int32_t)lo : -1;
-            if (!found) miss++;
         }
-        if (miss) atomicAdd(&s_miss, miss);
     }
+    const u64 nm = (u64)__popcll(__ballot(missed));
+    if ((threadIdx.x & 63) == 0 && nm) atomicAdd((unsigned long long *)&scratch[1], (unsigned long long)nm);
+    __threadfence();
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) s_last = atomicAdd((unsigned long long *)&scratch[0], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    const u64 misses = atomicExch((unsigned long long *)&scratch[1], 0ull);
+    scratch[0] = 0ull;
     int64_t flags = caller_flags ? 8 : 0;
     if (tot[3] != 0 || tot[1] > (u64)cap_v || tot[7] > tot[1]) flags |= 1;
     if (tot[4] != 0) flags |= 2;
     if (tot[7] > (u64)cap_top) flags |= 4;
     summary[0] = (flags & 1) ? 0 : (int64_t)(tot[1] - tot[7]);
-    summary[1] = (int64_t)s_miss;
+    summary[1] = (int64_t)misses;
     summary[2] = flags;
     summary[3] = (int64_t)tot[1];
     summary[4] = (int64_t)tot[7];
@@ -703,11 +713,14 @@ __global__ __launch_bounds__(1024) void slab_lookup_summary_kernel(const float *
 }
 
 TOMO_API int tomo_slab_lookup_summary(const float *uniq, const unsigned long long *tot, int64_t cap_v, const float *msg, int64_t cap,
-                                      int32_t *out, int64_t cap_top, int64_t caller_flags, int64_t *summary, void *stream)
+                                      int32_t *out, int64_t cap_top, int64_t caller_flags, unsigned long long *scratch, int64_t *summary,
+                                      void *stream)
 {
-    if (!uniq || !tot || !summary || cap_v < 1 || cap_top < 0 || (msg && (!out || cap < 1))) return TOMO_E_ARG;
-    hipLaunchKernelGGL(slab_lookup_summary_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, uniq, (const u64 *)tot, cap_v, msg,
-                       cap, out, cap_top, caller_flags, summary);
+    if (!uniq || !tot || !summary || !scratch || cap_v < 1 || cap_top < 0 || (msg && (!out || cap < 1))) return TOMO_E_ARG;
+    const int64_t blocks = msg ? ceil_div64(cap, 256) : 1;
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(slab_lookup_summary_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, uniq, (const u64 *)tot,
+                       cap_v, msg, cap, out, cap_top, caller_flags, (u64 *)scratch, summary);
     return tomo_status();
 }
 

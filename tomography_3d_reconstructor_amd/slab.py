@@ -483,12 +483,19 @@ class HipEngine:
         return out
 
     def slab_lookup_summary(self, uniq, tot, cap_v, msg_in, cap, cap_top, caller_flags, summary):
-        """slab_lookup + slab_summary in one launch; `summary` = int64[8] to fill (e.g. this rank's row of the gathered table)."""
+        """slab_lookup + slab_summary in one launch; `summary` = int64[8] to fill."""
         from . import _lib
+        key = (str(uniq.device), torch.cuda.current_stream().cuda_stream)
+        scratch = self._ls_scratch.get(key) if hasattr(self, "_ls_scratch") else None
+        if scratch is None:                         # two ticket / miss words per stream, zeroed once: every call leaves them zero
+            if not hasattr(self, "_ls_scratch"):
+                self._ls_scratch = {}
+            scratch = self._ls_scratch[key] = torch.zeros(2, dtype=torch.int64, device=uniq.device)
         out = None if msg_in is None else torch.empty(max(cap, 1), dtype=torch.int32, device=uniq.device)
         _lib.check(_lib.lib().tomo_slab_lookup_summary(uniq.data_ptr(), tot.data_ptr(), cap_v, None if msg_in is None else msg_in.data_ptr(),
                                                        cap, None if out is None else out.data_ptr(), cap_top, caller_flags,
-                                                       summary.data_ptr(), torch.cuda.current_stream().cuda_stream), "tomo_slab_lookup_summary")
+                                                       scratch.data_ptr(), summary.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "tomo_slab_lookup_summary")
         return out
 
     def download(self, t):
