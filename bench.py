@@ -19,13 +19,14 @@ Workloads (BASELINE.json configs; sizes are width x height x slices there, (nz, 
            -- a FIXED total volume cut into N Z-slabs (STRONG scaling; N = 1 runs the whole stack on one GPU).
 
 Prints ONE JSON line (rank 0) with metric/value/unit..., plus
-  roofline:      the field ("SDF") kernel: `achieved`/`frac` = algorithmic 5 B per padded voxel / measured kernel time
-                 (HIP events on the launch stream, inside the timed region) vs the 8 TB/s HBM3E peak; `frac_traffic` =
-                 the same with the bytes the kernel actually moves (rocprofv3 counters, separate passes; the kernel
-                 reads the bit-packed volume, not the 1 B/voxel mask -- that is read by pack_close_kernel);
+  roofline:      the field ("SDF") kernel: `achieved`/`frac` = the bytes the kernel MOVES (rocprofv3 counter bytes of this
+                 command where committed, else 4 B x padded-pitch voxels written + the bit volume read) / measured kernel
+                 time (HIP events on the launch stream, inside the timed region) vs the 8 TB/s HBM3E peak; `frac_survey` =
+                 the same with SURVEY 8(d)'s 5 B per padded voxel (which credits it with the mask bytes pack_close_kernel reads);
   pass_floor:    the whole pass against its own HBM floor (1 B mask in + 4 B field out per voxel);
-  cold_pass_ms, host_to_host_ms: one pass without the size hints of earlier passes; the three drop-in class methods
-                 host list in -> host arrays out (PCIe inclusive) -- reported beside `value`, never as `value`;
+  cold_pass_ms, host_to_host_cold_ms / host_to_host_ms: one pass without the size hints of earlier passes; the three
+                 drop-in class methods host list in -> host arrays out (PCIe inclusive), FIRST call of the process and warm
+                 -- reported beside `value`, never as `value`;
   cpu_baseline:  the CPU oracle (a C/NumPy restatement of the reference, single thread) on a bounded sample;
   comm (N > 1):  ranks / distinct devices seen by the process group, halo bytes and time per pass.
 """
@@ -44,8 +45,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 WORKLOADS = {"cfg3": (1024, 1024, 1024), "cfg4": (2048, 1024, 1024), "cfg5": (4096, 2048, 2048)}
 CONFIG_INDEX = {"cfg3": 2, "cfg4": 3, "cfg5": 4}
-FIELD_PMC = os.path.join("profiles", "r02_field_pmc.json")      # written by tools/profile_round.sh (rocprofv3 --pmc passes)
-FIELD_PMC_OLD = os.path.join("profiles", "r01_field_pmc.json")
+# written by tools/profile_round.sh (rocprofv3 --pmc passes of this command); the newest one that exists is used
+FIELD_PMCS = [os.path.join("profiles", "r%02d_field_pmc.json" % r) for r in (3, 2, 1)]
 
 
 def parse(argv=None):
@@ -105,6 +106,26 @@ def launch_plan(args, env, argv):
     return ("run", world)
 
 
+def supervise(cmd, env, run=subprocess.call):
+    """A rank launched by torch.distributed.run does not touch the GPU itself: it starts the real worker as a CHILD process
+    and relays its exit code.  RCCL's C API (rccl.py, the default transport of the Z-slab job) has no timeout of its own; a
+    worker whose watchdog finds no progress for two minutes -- communicator creation, preflight, a pass -- leaves with code 4,
+    and every rank's supervisor then starts ONE fresh worker that uses torch.distributed's collectives instead
+    (TOMO_RCCL_DIRECT=0) on a fresh rendezvous (next port, store hosted by rank 0's worker).  A hang is collective, so all
+    ranks take the same decision.  `run` is injectable for the CPU tests."""
+    env = dict(env)
+    env["TOMO_BENCH_WORKER"] = "1"
+    rc = run(cmd, env=env)
+    if rc == 4 and env.get("TOMO_RCCL_DIRECT", "1") not in ("", "0"):
+        print("bench.py: rank %s: the worker gave up (no progress) -- one retry over torch.distributed's collectives"
+              % env.get("RANK", "?"), file=sys.stderr, flush=True)
+        env["TOMO_RCCL_DIRECT"] = "0"
+        env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        rc = run(cmd, env=env)
+    return rc
+
+
 def workload_shape(args, world):
     """-> (total (gz, ny, nx), scaling, name)."""
     if args.workload != "default":
@@ -124,6 +145,7 @@ class FieldTimer:
     def __init__(self, torch, lib):
         self.pairs = []
         self.padded_voxels = 0
+        self.field_bytes = self.bit_bytes = 0
         self.enabled = False
         self.torch = torch
         timer = self
@@ -140,6 +162,8 @@ class FieldTimer:
                 timer.pairs.append((e0, e1))
                 nz, ny, nx, pad = a[2], a[3], a[4], a[5]
                 timer.padded_voxels = (nz + 2 * pad) * (ny + 2 * pad) * (nx + 2 * pad)
+                timer.field_bytes = 4 * (nz + 2 * pad) * (ny + 2 * pad) * int(lib.tomo_field_pitch(nx, pad))
+                timer.bit_bytes = nz * ny * int(lib.tomo_words_per_row(nx)) * 8
                 return rc
             return wrapped
 
@@ -433,26 +457,36 @@ def run(args, world):
     fms = timer.mean_ms()
     roofline = None
     if fms:
-        alg = 5.0 * timer.padded_voxels              # 1 B mask + 4 B field per padded voxel of the launch (rank 0)
-        ach = alg / (fms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "field_tile_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes": alg, "kernel_ms": round(fms, 4),
-                    "note": "achieved/frac: SURVEY 8(d)'s 5 B per padded voxel (1 B mask + 4 B f32) / kernel time. The kernel itself "
-                            "reads the bit-packed volume (1/8 B per voxel); the 1 B/voxel mask is read by pack_close_kernel. "
-                            "frac_traffic prices the kernel by the bytes it moves."}
-        pmc = next((p for p in (FIELD_PMC, FIELD_PMC_OLD) if os.path.exists(os.path.join(ROOT, p))), None)
+        # What the kernel MOVES: it writes the float32 field in whole 128-byte lines (4 B x Nz x Ny x pitch) and reads the
+        # bit-packed volume (1/8 B per voxel; the 1 B/voxel mask is read by pack_close_kernel, not here) -- `touched`, from the
+        # geometry of the launch; for the 1024^3 workload the rocprofv3 counter bytes of the same command are used instead
+        # (`traffic`, separate --pmc passes).  SURVEY 8(d) prices the kernel at 5 B per padded voxel (1 B mask + 4 B f32): kept
+        # as achieved_survey / frac_survey.
+        alg = 5.0 * timer.padded_voxels
+        touched = float(timer.field_bytes + timer.bit_bytes)
+        pmc = next((p for p in FIELD_PMCS if os.path.exists(os.path.join(ROOT, p))), None)
+        traffic = None
         if not dist and pmc and (gz, ny, nx) == (1024, 1024, 1024) and not args.sparse_field:
-            traffic = json.load(open(os.path.join(ROOT, pmc)))["hbm_bytes_per_launch"]
-            roofline["traffic"] = traffic
-            roofline["traffic_source"] = "%s (separate rocprofv3 --pmc passes of this command, not measured in this run)" % pmc
-            roofline["achieved_traffic"] = round(traffic / (fms * 1e-3) / 1e9, 1)
-            roofline["frac_traffic"] = round(traffic / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            traffic = float(json.load(open(os.path.join(ROOT, pmc)))["hbm_bytes_per_launch"])
+        moved = traffic if traffic is not None else touched
+        ach = moved / (fms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "field_tile_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": moved, "kernel_ms": round(fms, 4),
+                    "bytes_source": ("%s (HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                     "gfx950 corrections applied; not measured in this run)" % pmc) if traffic is not None else
+                                    "geometry of the launch: 4 B x Nz x Ny x pitch written + the bit-packed volume read once",
+                    "touched_bytes": touched,
+                    "algorithmic_bytes_survey": alg, "achieved_survey": round(alg / (fms * 1e-3) / 1e9, 1),
+                    "frac_survey": round(alg / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "achieved / frac: the bytes the kernel moves / kernel time (HIP events on the launch stream, inside the timed "
+                            "region) vs the 8 TB/s HBM3E peak.  *_survey: SURVEY 8(d)'s 5 B per padded voxel (1 B mask + 4 B f32), which "
+                            "credits the kernel with the mask bytes that pack_close_kernel reads."}
         if args.sparse_field and not dist:
             # the dense figure does not describe this run: most of the field is never written
             roofline = {"bound": "hbm", "kernel": "field_span/comb/worklist/tile kernels (tile-sparse fill)", "achieved": None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "algorithmic_bytes": alg, "kernel_ms": round(fms, 4),
+                        "algorithmic_bytes_survey": alg, "kernel_ms": round(fms, 4),
                         "note": "opt-in sparse field: ~7 % of the tiles are written; the dense 5 B/voxel figure does not apply"}
     nverts = int(res[0].shape[0]) if res else 0
     nfaces = int(res[1].shape[0]) if res else 0
@@ -554,6 +588,10 @@ def main(argv=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "4")
         return subprocess.call(plan[1], env=env)
+    if plan[1] > 1 and args.backend == "nccl" and not os.environ.get("TOMO_BENCH_WORKER"):
+        # a rank of a multi-GPU run: supervise a worker child (this process never initialises the GPU, so this is a child
+        # process, not an exec of a GPU process)
+        return supervise([sys.executable, os.path.abspath(__file__)] + list(argv), os.environ)
     run(args, plan[1])
     return 0
 

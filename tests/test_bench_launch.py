@@ -58,3 +58,27 @@ def test_refusal_exit_code(monkeypatch):
 def test_workloads(argv, world, total, scaling):
     shape, sc, _ = bench.workload_shape(bench.parse(argv), world)
     assert shape == total and sc == scaling
+
+
+def test_rank_supervisor_retries_once_over_the_process_group():
+    """bench.supervise: a worker that gives up with code 4 (the watchdog's: no progress for two minutes) is replaced ONCE by a
+    worker on torch.distributed's collectives and a fresh rendezvous; any other exit code is handed on unchanged."""
+    calls = []
+
+    def fake(codes):
+        def run(cmd, env):
+            calls.append((list(cmd), dict(env)))
+            return codes.pop(0)
+        return run
+    env = {"RANK": "3", "WORLD_SIZE": "8", "MASTER_PORT": "29511", "TORCHELASTIC_USE_AGENT_STORE": "True"}
+    assert bench.supervise(["x"], env, fake([4, 0])) == 0
+    assert len(calls) == 2 and calls[0][1]["TOMO_BENCH_WORKER"] == "1" and "TOMO_RCCL_DIRECT" not in calls[0][1]
+    assert calls[1][1]["TOMO_RCCL_DIRECT"] == "0" and calls[1][1]["MASTER_PORT"] == "29512"
+    assert "TORCHELASTIC_USE_AGENT_STORE" not in calls[1][1] and calls[1][1]["TOMO_BENCH_WORKER"] == "1"
+    del calls[:]
+    assert bench.supervise(["x"], env, fake([4, 4])) == 4 and len(calls) == 2          # one retry, not a loop
+    del calls[:]
+    assert bench.supervise(["x"], env, fake([1])) == 1 and len(calls) == 1             # a crash is not a hang
+    del calls[:]
+    assert bench.supervise(["x"], dict(env, TOMO_RCCL_DIRECT="0"), fake([4])) == 4 and len(calls) == 1   # nothing left to fall back to
+    assert env == {"RANK": "3", "WORLD_SIZE": "8", "MASTER_PORT": "29511", "TORCHELASTIC_USE_AGENT_STORE": "True"}

@@ -163,3 +163,36 @@ def test_slab_range_partition():
             rs = [slab.slab_range(gz, r, w) for r in range(w)]
             assert rs[0][0] == 0 and rs[-1][1] == gz
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+
+
+def test_export_obj_failure_is_raised_on_every_rank(tmp_path):
+    """A path only rank 0 finds unwritable (it creates the file) must not leave the other ranks waiting in the next
+    all-gather: the error flag travels with the gathers, EVERY rank raises, and no partial file stays behind."""
+    world, shape = 2, (48, 24, 40)
+    v = make_volume(1, shape)
+    depths = np.full(shape[0], 0.5)
+    comms = slab.ThreadComm.make(world)
+    bad_path = str(tmp_path / "no_such_directory" / "slab.obj")
+    raised, errs = [None] * world, []
+
+    def target(c):
+        try:
+            job = slab.SlabJob(shape[0], shape[1], shape[2], c, engine=OracleEngine())
+            job.run(torch.from_numpy(v[job.z0:job.z1].astype(np.uint8)), depths, 1.0, 1.0)
+            try:
+                job.export_obj(bad_path, nthreads=1)
+            except OSError as e:
+                raised[c.rank] = e
+            # the job is still usable: the same export to a good path works afterwards
+            assert job.export_obj(str(tmp_path / "good.obj"), nthreads=1) > 0
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            raise
+
+    ts = [threading.Thread(target=target, args=(c,)) for c in comms]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting in a collective step"
+    assert not errs, errs
+    assert all(isinstance(e, OSError) and "creating the file" in str(e) for e in raised), raised
+    assert not os.path.exists(bad_path)

@@ -99,6 +99,11 @@ def get(arr):
     return vol
 
 
+def invalidate(arr):
+    """Forget the device copy remembered for `arr` (its content can no longer be vouched for)."""
+    _cache.pop(id(arr), None)
+
+
 def _base_writeable(arr):
     b = arr.base
     while isinstance(b, np.ndarray):

@@ -385,8 +385,7 @@ __device__ static inline u64 word_flood(u64 s, u64 m)
 }
 
 #define FH_THREADS 1024
-__global__ __launch_bounds__(FH_THREADS) void fill_holes_kernel(u64 *slice, u64 *reach,
-                                                                int ny, int nx, int wx)
+__device__ static inline void fill_holes_one_workgroup(u64 *slice, u64 *reach, int ny, int nx, int wx)
 {
     __shared__ int s_any, s_changed;
     const int tid = threadIdx.x;
@@ -455,6 +454,30 @@ __global__ __launch_bounds__(FH_THREADS) void fill_holes_kernel(u64 *slice, u64 
     }
 }
 
+__global__ __launch_bounds__(FH_THREADS) void fill_holes_kernel(u64 *slice, u64 *reach, int ny, int nx, int wx)
+{
+    fill_holes_one_workgroup(slice, reach, ny, nx, wx);
+}
+
+// Safety net behind fill_holes_bands_kernel (below): its grid barrier gives up when not all of its workgroups become
+// resident in time (a GPU shared with other streams or processes, a partitioned device) and the slice is then left
+// unfilled or partly filled, with ctrl[8 sl + 2] set.  This one-workgroup kernel runs right after it and redoes such a
+// slice with the flood above -- filling holes is idempotent and monotone, so a partly filled slice gives the same result
+// as the original.  The flags are read before `reach` (which overlaps the control words in scratch) is written.
+__global__ __launch_bounds__(FH_THREADS) void fill_holes_redo_kernel(u64 *sliceA, u64 *sliceB, u64 *ctrl, u64 *reach, int ny,
+                                                                     int nx, int wx)
+{
+    __shared__ int s_redo[2];
+    if (threadIdx.x < 2) s_redo[threadIdx.x] = ctrl[8 * threadIdx.x + 2] != 0ull;
+    __syncthreads();
+    const int ra = s_redo[0], rb = s_redo[1] && sliceB != nullptr;
+    if (!ra && !rb) return;
+    __syncthreads();
+    if (ra) fill_holes_one_workgroup(sliceA, reach, ny, nx, wx);
+    __syncthreads();
+    if (rb) fill_holes_one_workgroup(sliceB, reach, ny, nx, wx);
+}
+
 // ------------------------------------------------------------------------------------------
 // The same flood on MANY workgroups (the kernel above uses one CU of 256 and took 184 us for a filled 1024^2 ellipse,
 // 823 us at 2048^2 -- profiles/r02_fill_holes.md).  The slice is cut into bands of rows; a band (free mask F and reach
@@ -478,9 +501,10 @@ struct FillBands {
     u64 *ctrl;        // [2][8]: bar, any, err, -, flag[4]
     u64 *comp;        // [2][3][nb][wx]: Gd, Gu, P
     int ny, nx, wx, RB, nb;
+    int spin_limit;   // sleeps a workgroup waits at a grid barrier before it gives up (tests: TOMO_FILL_SPIN_LIMIT=0)
 };
 
-__device__ static inline bool fb_barrier(u64 *bar, u64 target)
+__device__ static inline bool fb_barrier(u64 *bar, u64 target, int spin_limit)
 {   // all workgroups of this slice; false if the wait was abandoned (never expected: every workgroup is resident)
     __syncthreads();
     __shared__ int ok;
@@ -491,7 +515,7 @@ __device__ static inline bool fb_barrier(u64 *bar, u64 target)
         ok = 1;
         while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 22)) { ok = 0; break; }
+            if (++spins > spin_limit) { ok = 0; break; }
         }
         __threadfence();
     }
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const Fill
         Gu[(size_t)b * wx + w] = R[w];
     }
     u64 k = 0;
-    if (!fb_barrier(&ctrl[0], (u64)nb * ++k)) { if (tid == 0) ctrl[2] = 1; return; }
+    if (!fb_barrier(&ctrl[0], (u64)nb * ++k, p.spin_limit)) { if (tid == 0) ctrl[2] = 1; return; }
     const int64_t max_rounds = (int64_t)p.ny * wx * 64 + 2;
     for (int64_t g = 0; g < max_rounds; g++) {
         if (tid == 0) s_chg = 0;
@@ -679,7 +703,7 @@ __global__ __launch_bounds__(FB_THREADS) void fill_holes_bands_kernel(const Fill
             // round g's flag word (reused four rounds later, when every workgroup is long past reading it)
             if (tid == 0) __hip_atomic_store(&ctrl[4 + (g & 3)], (u64)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!fb_barrier(&ctrl[0], (u64)nb * ++k)) { if (tid == 0) ctrl[2] = 1; return; }
+        if (!fb_barrier(&ctrl[0], (u64)nb * ++k, p.spin_limit)) { if (tid == 0) ctrl[2] = 1; return; }
         if (__hip_atomic_load(&ctrl[4 + (g & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u64)(g + 1)) break;
     }
     // holes = background not reached -> filled = everything not reached
@@ -703,25 +727,48 @@ static inline int fill_bands_plan(int ny, int wx, int *RB_out)
     return nb;
 }
 
+// Can nb * nsl workgroups of the banded kernel be resident at once on the current device?  (Its grid barrier needs that; the
+// answer is cached per LDS size.)  Occupancy per CU x CUs -- on a partitioned or smaller part the one-workgroup kernel runs.
+static bool fill_bands_fit(int blocks, size_t lds_bytes)
+{
+    static size_t cached_lds = 0;
+    static int cached_capacity = -1, cached_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (cached_capacity < 0 || cached_lds != lds_bytes || cached_dev != dev) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fill_holes_bands_kernel, FB_THREADS, lds_bytes) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        cached_capacity = per_cu * cus; cached_lds = lds_bytes; cached_dev = dev;
+    }
+    return blocks <= cached_capacity;
+}
+
 static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u64 *scratch, hipStream_t st,
                              bool ctrl_cleared = false)
 {
     int RB = 0;
-    const int nb = getenv("TOMO_FILL_ONE_BLOCK") ? 0 : fill_bands_plan(ny, wx, &RB);
+    int nb = fill_bands_plan(ny, wx, &RB);
     const int nsl = sliceB ? 2 : 1;
+    const size_t lds = ((size_t)2 * RB * wx + (size_t)4 * FB_FOLD * wx) * sizeof(u64);
     // scratch holds ny * wx + 8 words (the one-workgroup kernel's reach set): room for 16 control + 2 * 3 * nb * wx words?
-    if (nb == 0 || 16 + (int64_t)nsl * 3 * nb * wx > (int64_t)ny * wx + 8) {
+    if (nb == 0 || 16 + (int64_t)nsl * 3 * nb * wx > (int64_t)ny * wx + 8 || !fill_bands_fit(nb * nsl, lds)) {
         hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceA, scratch, ny, nx, wx);
         if (sliceB) hipLaunchKernelGGL(fill_holes_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceB, scratch, ny, nx, wx);
         return tomo_status();
     }
     if (!ctrl_cleared && hipMemsetAsync(scratch, 0, 16 * sizeof(u64), st) != hipSuccess) return TOMO_E_LAUNCH;
+    static const int spin_limit = getenv("TOMO_FILL_SPIN_LIMIT") ? atoi(getenv("TOMO_FILL_SPIN_LIMIT")) : (1 << 22);
     FillBands p;
     p.slice[0] = sliceA; p.slice[1] = sliceB ? sliceB : sliceA;
     p.ctrl = scratch; p.comp = scratch + 16;
-    p.ny = ny; p.nx = nx; p.wx = wx; p.RB = RB; p.nb = nb;
-    hipLaunchKernelGGL(fill_holes_bands_kernel, dim3((unsigned)nb, (unsigned)nsl), dim3(FB_THREADS),
-                       ((size_t)2 * RB * wx + (size_t)4 * FB_FOLD * wx) * sizeof(u64), st, p);
+    p.ny = ny; p.nx = nx; p.wx = wx; p.RB = RB; p.nb = nb; p.spin_limit = spin_limit;
+    hipLaunchKernelGGL(fill_holes_bands_kernel, dim3((unsigned)nb, (unsigned)nsl), dim3(FB_THREADS), lds, st, p);
+    // a barrier that was abandoned (never seen with every workgroup resident) must not leave a slice half filled
+    hipLaunchKernelGGL(fill_holes_redo_kernel, dim3(1), dim3(FH_THREADS), 0, st, sliceA, sliceB, scratch, scratch, ny, nx, wx);
     return tomo_status();
 }
 

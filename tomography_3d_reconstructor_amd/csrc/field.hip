@@ -60,6 +60,9 @@ struct FieldParams {
     // bit 1: a 0 within 3 voxels); list[0 .. *count) = linear ids of the blocks that have anything to do
     const unsigned char *comb;
     const u32 *list, *count;
+#ifdef FT_PROFILE
+    unsigned long long *prof;
+#endif
 };
 
 __device__ static inline double tap5(double a, double b, double c, double d, double e)
@@ -73,6 +76,15 @@ __device__ static inline double tap5(double a, double b, double c, double d, dou
 // dynamic LDS: u32 s_bits[FT_SLOTS][FT_SROWS][WS] | u32 s_ror[FT_SLOTS][WS] | u32 s_rand[FT_SLOTS][WS] |
 //              (8-byte aligned) u8 s_sign[FT_ZG][FT_ROWS][4][SB]
 extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
+
+#ifdef FT_PROFILE
+// tools/fieldprof.py: per-block phase time stamps (s_memtime) of field_tile_kernel -- a profiling build only
+static unsigned long long *g_ft_prof = nullptr;
+TOMO_API void tomo_field_profile_buffer(unsigned long long *buf) { g_ft_prof = buf; }
+#define FT_STAMP(k) do { if (p.prof && threadIdx.x == 0) p.prof[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FT_STAMP(k) do { } while (0)
+#endif
 
 // One 32-bit word of the EXTENDED bit volume (slice ez, row ey, word gw) from the plain bit volume -- what extend_kernel
 // (bits.hip) would have stored there: reflect of the padded array along z and y, a funnel shift by 4 + pad bits along x,
@@ -108,6 +120,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         s_lut[tid] = t;
     }
     if (tid == 0) { s_nmixed = 0; s_nnear = 0; }
+    FT_STAMP(0);
     // ---- which part of the field is this block's
     if (p.list != nullptr && blockIdx.x >= *p.count) return;
     const unsigned lin = p.list != nullptr ? p.list[blockIdx.x] : blockIdx.x;
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         }
     }
     __syncthreads();
+    FT_STAMP(1);
     // ---- per (slot, word): OR / AND over the 20 staged rows
     for (int it = tid; it < FT_SLOTS * WS; it += FT_THREADS) {
         const int slot = it / WS, w = it - slot * WS;
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
         if (c == 2) s_list[atomicAdd(&s_nmixed, 1)] = (unsigned short)((z << 8) | jl);
     }
     __syncthreads();
+    FT_STAMP(2);
 
     // constants of the all-ones interior, produced by the same operation sequence
     const double p1one = s_lut[17];
@@ -315,6 +330,10 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
     // ---- mixed tiles: six per wave pass, ten lanes per tile (lanes 1..8 own the tile's 32 columns, lanes 0 and 9
     //      compute the pass-2 values of the halo columns)
     const int nmixed = s_nmixed;
+    FT_STAMP(3);
+#ifdef FT_PROFILE
+    if (p.prof && tid == 0) p.prof[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nmixed | ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
     const int SS = FT_SROWS * WS;                   // LDS slot stride
     for (int ch = wave; ch * 6 < nmixed; ch += nwaves) {
         const int g = lane / 10, l = lane - 10 * g;
@@ -392,9 +411,12 @@ __global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__res
 #undef CODES
 #undef SPREAD
     }
+    FT_STAMP(4);
     if (p.signs == nullptr) return;
     __syncthreads();
+    FT_STAMP(5);
     write_signs();
+    FT_STAMP(6);
 }
 
 // manifold=False: the field is the raw 0/1 volume (surface_extractor.py:46 without the Gaussian).
@@ -437,6 +459,9 @@ static size_t fill_params(FieldParams &p, int nz, int ny, int nx, int pad, unsig
     p.signs = (u64 *)signs;
     p.gcls = gcls;
     p.comb = nullptr; p.list = nullptr; p.count = nullptr;
+#ifdef FT_PROFILE
+    p.prof = g_ft_prof;
+#endif
     int ntmax = p.NT < p.tp ? p.NT : p.tp;           // tiles of the widest block
     int WS = ntmax + 1;
     size_t words = (((size_t)(FT_SLOTS * FT_SROWS + 2 * FT_SLOTS) * WS + 1) & ~(size_t)1);

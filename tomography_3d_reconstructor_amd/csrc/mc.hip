@@ -819,13 +819,16 @@ __global__ __launch_bounds__(256) void mc3_segsum_kernel(const u32 *__restrict__
 // ---- exclusive scan, in place, of K u32 arrays of n entries (a[k * stride + i]) by ONE workgroup of 1024 threads
 // (n = a few 10^4: block sums); total[k] = sum of array k.  8 consecutive entries per thread and round (two 16-byte loads),
 // wave scans, one more wave scan across the 16 wave totals.
+// total_out[k] is the sum in 64 bits: the prefixes themselves are 32-bit (what every consumer indexes with), so a caller must
+// treat a total beyond 2^32 - 1 as an overflow of its buffers (a round of 8192 entries cannot wrap: block sums are < 2^19).
 template <int K>
-__device__ static inline void scan_small_inplace(u32 *__restrict__ a, int64_t stride, int64_t n, u32 *total_out, u32 *lds /* K * 16 + K */)
+__device__ static inline void scan_small_inplace(u32 *__restrict__ a, int64_t stride, int64_t n, u64 *total_out, u32 *lds /* K * 16 + K */)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 carry[K];
+    u64 wide[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) carry[k] = 0;
+    for (int k = 0; k < K; k++) { carry[k] = 0; wide[k] = 0; }
     for (int64_t base = 0; base < n; base += 1024 * 8) {
         const int64_t i0 = base + (int64_t)threadIdx.x * 8;
         u32 v[K][8], s[K];
@@ -874,21 +877,23 @@ __device__ static inline void scan_small_inplace(u32 *__restrict__ a, int64_t st
                 for (int j = 0; j < 8; j++) { if (i0 + j < n) p[j] = ex; ex += v[k][j]; }
             }
             carry[k] += lds[K * 16 + k];
+            wide[k] += lds[K * 16 + k];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < K; k++) total_out[k] = carry[k];
+    for (int k = 0; k < K; k++) total_out[k] = wide[k];
 }
 
 __global__ __launch_bounds__(1024) void mc3_scan_seg_kernel(u32 *__restrict__ seg_blk, int64_t nblk, u64 *__restrict__ tot)
 {
     __shared__ u32 lds[17];
-    u32 total;
+    u64 total;
     scan_small_inplace<1>(seg_blk, 0, nblk, &total, lds);
     if (threadIdx.x == 0) {
-        tot[0] = total;
-        tot[1] = tot[2] = tot[3] = tot[4] = tot[5] = tot[6] = tot[7] = 0ull;
+        tot[0] = total;                                           // exact even beyond 2^32: the host then reports "surface too large"
+        tot[1] = tot[2] = tot[4] = tot[5] = tot[6] = tot[7] = 0ull;
+        tot[3] = total > 0xffffffffull ? 1ull : 0ull;             // the 32-bit prefixes have wrapped: nothing downstream may be trusted
     }
 }
 
@@ -912,7 +917,10 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_list_kernel(const McGrid g, const
     seg_aoff[seg] = o;
     if (seg == nseg - 1) seg_aoff[nseg] = o + cnt;
     if (cnt == 0) return;                                       // empty: its ballot record was never written
-    if (o + cnt > cap) { if (o <= cap) atomicOr((unsigned long long *)&tot[3], 1ull); return; }   // the list does not fit: flagged, nothing written
+    if ((u64)o + cnt > (u64)cap || tot[0] > (u64)cap) {           // the list does not fit (or its 32-bit offsets have wrapped): flagged, nothing written
+        if (o <= cap) atomicOr((unsigned long long *)&tot[3], 1ull);
+        return;
+    }
     int64_t row;
     const int s = divmod_pos(seg, g.segs_per_row, &row);
     const ulonglong2 *q = (const ulonglong2 *)(seg_act + seg * 4);
@@ -1027,10 +1035,11 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
                                                         int64_t cap_v, int64_t cap_f)
 {
     __shared__ u32 lds[3 * 16 + 3];
-    u32 totals[3];
+    u64 totals[3];
     scan_small_inplace<3>(blk3, nblk, nblk, totals, lds);       // ends with a barrier: the prefixes are visible to every thread
     const u64 na = tot[0];
-    const u32 totA = totals[0], totB = totals[1], totT = totals[2];
+    const u64 totA64 = totals[0], totB64 = totals[1], totT64 = totals[2];
+    const u32 totA = (u32)totA64, totB = (u32)totB64;
     const int Nz = g.Nz;
     u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1), *offsets = slice_tab + 2 * (Nz + 1);
     const int64_t segs_per_slice = (int64_t)g.Ny * g.segs_per_row;
@@ -1050,8 +1059,8 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
     }
     __syncthreads();
     u64 ov = 0;
-    if ((u64)totA + totB > (u64)cap_v) ov |= 2ull;
-    if ((u64)totT > (u64)cap_f) ov |= 4ull;
+    if (totA64 + totB64 > (u64)cap_v) ov |= 2ull;
+    if (totT64 > (u64)cap_f) ov |= 4ull;
     if (!fits) ov |= 1ull;
     for (int Z = threadIdx.x; Z < Nz; Z += 1024) {           // on overflow every bucket is empty: the sort touches nothing
         offsets[2 * Z] = ov ? 0u : sliceA[Z] + sliceB[Z];
@@ -1059,8 +1068,8 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
     }
     if (threadIdx.x == 0) {
         offsets[2 * Nz] = ov ? 0u : totA + totB;
-        tot[1] = (u64)totA + totB;
-        tot[2] = totT;
+        tot[1] = totA64 + totB64;
+        tot[2] = totT64;
         if (ov) atomicOr((unsigned long long *)&tot[3], (unsigned long long)ov);
     }
 }

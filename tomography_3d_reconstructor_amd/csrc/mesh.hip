@@ -375,8 +375,7 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
     hipStream_t s = (hipStream_t)stream;
     unsigned blocks = (unsigned)ceil_div64(nv, 256);
     UqOrder order{(const u32 *)idx_c, nullptr, nullptr};
-    static const bool global_sort = getenv("TOMO_UQ_GLOBAL_SORT") != nullptr;     // A/B switch: one 48-bit device-wide sort
-    if (global_sort || Nz <= 0 || Nz > UQ_MAX_SLABS) {
+    if (Nz <= 0 || Nz > UQ_MAX_SLABS) {
         hipLaunchKernelGGL(uq_keys_bucket_kernel, dim3(blocks), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, TOMO_KEY_ROW_SHIFT, Ny,
                            kzy_a, idx_b);
         if (rocprim::radix_sort_pairs(temp, tb, kzy_a, kzy_b, idx_b, idx_c, (size_t)nv, 0, 48, s) != hipSuccess) return TOMO_E_LAUNCH;
@@ -395,15 +394,9 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
         hipLaunchKernelGGL(uq_partition_kernel, dim3(blocks2), dim3(256), 0, s, vpos, (const u64 *)vkey, nv, Ny, Nz,
                            (const u32 *)Bscan, (const u32 *)slab_start, kx_a, idx_b, offsets);
         tb = L.temp_bytes;
-        static const bool stock = getenv("TOMO_UQ_STOCK_SORTCFG") != nullptr;       // A/B switch: rocPRIM's default configuration
-        hipError_t e;
-        if (stock)
-            e = rocprim::segmented_radix_sort_pairs(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
-                                                    (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s);
-        else
-            e = rocprim::segmented_radix_sort_pairs<UqSegCfg>(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
-                                                              (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s);
-        if (e != hipSuccess) return TOMO_E_LAUNCH;
+        if (rocprim::segmented_radix_sort_pairs<UqSegCfg>(temp, tb, kx_a, kx_b, idx_b, idx_c, (unsigned)nv, (unsigned)(2 * Nz),
+                                                          (const u32 *)offsets, (const u32 *)offsets + 1, 0, 32, s) != hipSuccess)
+            return TOMO_E_LAUNCH;
         if (Nz >= 2) {                              // the clamped run of slab 0 and the plane of slab 1 (see uq_merge_kernel)
             hipLaunchKernelGGL(uq_merge_kernel, dim3(256), dim3(256), 0, s, vpos, (const u32 *)offsets, (const u32 *)idx_c, idx_b);
             order.alt = idx_b;

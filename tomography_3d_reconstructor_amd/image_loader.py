@@ -19,6 +19,7 @@ import glob
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import torch
@@ -128,15 +129,25 @@ class ImageLoader:
                 return False
             masks = grey >= threshold                               # one contiguous bool (n, H, W) array
             if on_gpu and exact:
-                dev = torch.device("cuda", torch.cuda.current_device())
-                # integer grey levels: g >= t  <=>  g >= ceil(t)
-                vol = pipeline.pack_threshold(backing.to(dev, non_blocking=True), math.ceil(threshold))
-                torch.cuda.current_stream().synchronize()           # the pinned block may go once this returns
-                # write-protect the stack BEFORE the per-slice views exist: they inherit the flag, and the remembered
-                # device copy can then never differ from what the caller sees
-                _devcache.put(masks, vol)
+                # the device copy is an optimisation of the NEXT step (create_voxel_data need not upload): if it cannot be
+                # made -- out of device memory, say -- the masks are still loaded, exactly as the host-only reference's are;
+                # only "no usable GPU / library" is reported, as everywhere in this package
+                try:
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    # integer grey levels: g >= t  <=>  g >= ceil(t)
+                    vol = pipeline.pack_threshold(backing.to(dev, non_blocking=True), math.ceil(threshold))
+                    torch.cuda.current_stream().synchronize()       # the pinned block may go once this returns
+                    # write-protect the stack BEFORE the per-slice views exist: they inherit the flag, and the remembered
+                    # device copy can then never differ from what the caller sees
+                    _devcache.put(masks, vol)
+                except pipeline._lib.TomoUnavailable:
+                    raise
+                except Exception as e:                              # noqa: BLE001
+                    print(f"tomography_3d_reconstructor_amd: masks kept on the host only ({e})", file=sys.stderr)
             self.mask_images = [masks[i] for i in range(self.num_slices)]
             return True
+        except pipeline._lib.TomoUnavailable:
+            raise
         except Exception as e:                                      # noqa: BLE001 -- the reference reports and returns False
             print(f"Loading failed: {e}")
             return False

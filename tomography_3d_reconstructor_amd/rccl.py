@@ -63,11 +63,19 @@ class RcclComm:
         self.rank, self.world = td.get_rank(), td.get_world_size()
         L = lib()
         uid = _UniqueId()
+        # rank 0's id travels together with its verdict: a failure there becomes the SAME exception on every rank instead of
+        # rank 0 leaving the broadcast the others wait in
+        box = [None, None]
         if self.rank == 0:
-            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [ctypes.string_at(ctypes.addressof(uid), 128) if self.rank == 0 else None]      # the raw 128 bytes (NULs included)
+            try:
+                _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+                box = [ctypes.string_at(ctypes.addressof(uid), 128), None]                   # the raw 128 bytes (NULs included)
+            except Exception as e:                                                         # noqa: BLE001
+                box = [None, repr(e)]
         if self.world > 1:
             td.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RuntimeError("rank 0 could not create an ncclUniqueId: %s" % box[1])
         ctypes.memmove(ctypes.addressof(uid), box[0], 128)
         self._comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):

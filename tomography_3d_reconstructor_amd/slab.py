@@ -959,33 +959,57 @@ class SlabJob:
         f = np.ascontiguousarray(faces.detach().cpu().numpy(), dtype=np.int64).reshape(-1, 3)
         nt = int(nthreads or max(1, min(16, (os.cpu_count() or 1) // max(self.world, 1))))
         blocks = []
+
+        def agree(row, what):
+            """All-gather one int64 row per rank whose LAST entry is this rank's error flag; a failure on ANY rank becomes the
+            same exception on EVERY rank (nobody is left waiting in the next collective step) and rank 0 removes the file."""
+            table = torch.stack(self.comm.all_gather(torch.tensor(row, dtype=torch.int64, device=dev))).cpu().numpy()
+            bad = [r for r in range(self.world) if table[r, -1]]
+            if bad:
+                if self.rank == 0:
+                    try:
+                        os.unlink(path)
+                    except OSError:
+                        pass
+                raise OSError("export_obj: %s failed on rank(s) %s%s" % (what, bad, (": %r" % (err[0],)) if err else ""))
+            return table
+
+        err = []
         try:
             import ctypes
             sizes = []
-            for kind, rows in ((0, v), (2, f)):
-                h, nb = ctypes.c_void_p(), ctypes.c_int64()
-                _lib.check(L.tomo_obj_block_format(kind, rows.ctypes.data if len(rows) else None, len(rows), nt,
-                                                   ctypes.byref(h), ctypes.byref(nb)), "tomo_obj_block_format")
-                blocks.append(h)
-                sizes.append(int(nb.value))
-            table = torch.stack(self.comm.all_gather(torch.tensor(sizes + [len(v), len(f)], dtype=torch.int64, device=dev))).cpu().numpy()
+            try:
+                for kind, rows in ((0, v), (2, f)):
+                    h, nb = ctypes.c_void_p(), ctypes.c_int64()
+                    _lib.check(L.tomo_obj_block_format(kind, rows.ctypes.data if len(rows) else None, len(rows), nt,
+                                                       ctypes.byref(h), ctypes.byref(nb)), "tomo_obj_block_format")
+                    blocks.append(h)
+                    sizes.append(int(nb.value))
+            except Exception as e:                                    # noqa: BLE001  (out of memory while formatting, ...)
+                err.append(e)
+                sizes = (sizes + [0, 0])[:2]
+            table = agree(sizes + [len(v), len(f), 1 if err else 0], "formatting")
             header = b"# Tomography reconstruction model\n# %d vertices, %d faces\n\n" % (int(table[:, 2].sum()), int(table[:, 3].sum()))
             v_at = len(header) + int(table[: self.rank, 0].sum())
             sep_at = len(header) + int(table[:, 0].sum())
             f_at = sep_at + 1 + int(table[: self.rank, 1].sum())
             total = sep_at + 1 + int(table[:, 1].sum())
             if self.rank == 0:
-                with open(path, "wb") as fh:
-                    fh.write(header)
-                    fh.truncate(total)
-                    fh.seek(sep_at)
-                    fh.write(b"\n")
-            self.comm.all_gather(torch.zeros(1, dtype=torch.int64, device=dev))          # the file exists before anyone writes into it
+                try:
+                    with open(path, "wb") as fh:
+                        fh.write(header)
+                        fh.truncate(total)
+                        fh.seek(sep_at)
+                        fh.write(b"\n")
+                except OSError as e:                                  # an unwritable path, a full disk
+                    err.append(e)
+            agree([1 if err else 0], "creating the file")             # the file exists before anyone writes into it
             for h, at in zip(blocks, (v_at, f_at)):
                 rc = L.tomo_obj_block_pwrite(os.fsencode(path), at, h)
                 if rc:
-                    raise OSError(-rc, os.strerror(-rc), path) if rc < -1 else _lib.TomoError("tomo_obj_block_pwrite")
-            self.comm.all_gather(torch.zeros(1, dtype=torch.int64, device=dev))          # complete on return, on every rank
+                    err.append(OSError(-rc, os.strerror(-rc), path) if rc < -1 else _lib.TomoError("tomo_obj_block_pwrite"))
+                    break
+            agree([1 if err else 0], "writing")                       # complete on return, on every rank
             return total
         finally:
             for h in blocks:

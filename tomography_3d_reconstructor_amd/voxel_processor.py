@@ -25,6 +25,11 @@ def to_device_volume(voxel_data):
     vol = _devcache.get(voxel_data) if isinstance(voxel_data, np.ndarray) else None
     if vol is not None:
         return vol
+    return upload_volume(voxel_data)
+
+
+def upload_volume(voxel_data):
+    """ndarray (nz,ny,nx) -> a FRESH BitVolume (never the cached one: the caller may overwrite it)."""
     a = np.ascontiguousarray(voxel_data)
     if a.ndim != 3:
         raise ValueError("voxel data must be 3-D")
@@ -120,19 +125,22 @@ class VoxelProcessor:
         base = _common_base(mask_images)
         cached = _devcache.get(base) if base is not None else None
         if cached is not None and not base.flags.writeable and any(m.flags.writeable for m in mask_images):
-            cached = None          # writeable views of a protected stack: its content may have changed behind the flag
+            # writeable views of a protected stack: its content may have changed behind the flag -- the remembered device
+            # copy is dropped for good (a later lookup must not find it either) and the stack is uploaded again
+            _devcache.invalidate(base)
+            cached = None
         if close_ends:
-            if cached is not None:                           # uploaded (and thresholded) by ImageLoader already
+            if cached is not None:                           # uploaded (and thresholded) by ImageLoader already: closed into a COPY
                 vol = pipeline.close_ends(cached)
             elif base is not None:
-                vol = pipeline.close_ends(to_device_volume(base), inplace=True)       # a fresh upload: ours to overwrite
+                vol = pipeline.close_ends(upload_volume(base), inplace=True)           # a fresh upload, never a cached volume: ours to overwrite
             else:
                 vol = pipeline.pack_closed(_stage_masks(mask_images))
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = to_host_volume(vol)
         else:
             stacked = np.stack(mask_images, axis=0)          # the reference returns a new array here
-            vol = cached if cached is not None else to_device_volume(stacked)
+            vol = cached if cached is not None else upload_volume(stacked)
             active = int(pipeline.popcount_async(vol).item())
             self.voxel_data = stacked
             _devcache.put(stacked, vol)
