@@ -259,3 +259,54 @@ def test_fractional_threshold_rounds_up(dev, tmp_path):
     assert np.array_equal(vol, grey >= 200)
     dv = pipeline.pack_threshold(torch.from_numpy(grey).to(dev), 199.5)
     assert np.array_equal(pipeline.unpack(dv).cpu().numpy(), grey >= 200)
+
+
+def test_cfg1_literal_half_ellipsoid_stack(dev, tmp_path):
+    """BASELINE configs[0] as written: "128x128x64 synthetic half-ellipsoid mask stack (simple_generator.py)".  One base mask
+    -> 48 copies as the main body (Section_1) and the two flanks written by generate_slices_from_mask
+    (/root/reference/simple_generator.py:6-20 -> ellipsoid_slice_generator.py:107-143; 8 slices each: Section_0 numbered
+    downwards from the body's first slice, Section_2 upwards from its last) -> PNG folders -> ImageLoader -> create / smooth /
+    extract on the HIP path, with the physical units of /root/reference/config.py:12-14 -- bytes-equal to the CPU oracle on
+    the same loaded masks.  (The generator's parity with OpenCV is unpinned -- SURVEY 8f N3 -- the path from the PNG files
+    on is not: the loader's masks equal the oracle's restatement of image_loader.py:37-120.)"""
+    from PIL import Image
+    from tomography_3d_reconstructor_amd.slice_generator import generate_slices_from_mask
+    ny = nx = 128
+    s0, s1, s2 = 8, 48, 8
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    base = (((xx - 63.5) / 46.0) ** 2 + ((yy - 63.5) / 38.0) ** 2) <= 1.0
+    body = tmp_path / "Section_1"
+    body.mkdir()
+    for k in range(1, s1 + 1):
+        Image.fromarray(np.where(base, 255, 0).astype(np.uint8), mode="L").save(body / ("Mask_Patient_%d.png" % k))
+    with contextlib.redirect_stdout(io.StringIO()) as said:
+        generate_slices_from_mask(str(body / "Mask_Patient_1.png"), s0, str(tmp_path / "Section_0"), 1, False)
+        generate_slices_from_mask(str(body / ("Mask_Patient_%d.png" % s1)), s2, str(tmp_path / "Section_2"), s1, True)
+    assert said.getvalue().count("Generated %d slices" % (s0 + 2)) == 2
+    assert len(os.listdir(tmp_path / "Section_0")) == s0 and len(os.listdir(tmp_path / "Section_2")) == s2
+    exp, counts, files = O.load_masks(str(tmp_path), 200)
+    ld = ImageLoader()
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert ld.load_mask_images(str(tmp_path), 200, [True, True, True]) is True
+    assert ld.get_side_counts() == counts == (s0, s1, s2) and ld.get_num_slices() == 64 and ld.get_image_dimensions() == (nx, ny)
+    masks = ld.get_mask_images()
+    assert all(np.array_equal(m, e) for m, e in zip(masks, exp))
+    areas = [int(m.sum()) for m in masks]
+    assert areas[:s0] == sorted(areas[:s0]) and areas[s0 + s1:] == sorted(areas[s0 + s1:], reverse=True)     # a half-ellipsoid at either end
+    assert 0 < areas[0] < areas[s0] == int(base.sum()) and areas[-1] < areas[s0]
+    mm_x, mm_y, depth = 143.1 / nx, 95.03 / ny, 6.0
+    vp, se, ovp, ose = VoxelProcessor(), SurfaceExtractor(), O.VoxelProcessor(), O.SurfaceExtractor()
+    with contextlib.redirect_stdout(io.StringIO()):
+        vol = vp.create_voxel_data(masks, True, s0, s1, s2)
+        depths = vp.calculate_slice_depths(depth)
+        sm = vp.smooth_voxel_data(vol, iterations=3, create_manifold=True)
+        res = se.extract_manifold_surface(sm, depths, mm_y, mm_x, smooth=True, manifold=True, add_padding=True)
+        ovol = ovp.create_voxel_data(exp, True, s0, s1, s2)
+        odepths = ovp.calculate_slice_depths(depth)
+        osm = ovp.smooth_voxel_data(ovol, 3, True)
+        ores = ose.extract_manifold_surface(osm, odepths, mm_y, mm_x)
+    assert np.array_equal(vol, ovol) and np.array_equal(sm, osm) and depths.tobytes() == odepths.tobytes()
+    assert res is not None and ores is not None
+    assert res[0].dtype == np.float32 and res[0].tobytes() == ores[0].tobytes(), "vertices differ from the oracle"
+    assert res[1].dtype == np.int64 and np.array_equal(res[1], ores[1]), "faces differ from the oracle"
+    assert len(res[0]) > 10000 and abs(se.calculate_mesh_volume(*res) - ose.calculate_mesh_volume(*ores)) <= 1e-6 * ose.calculate_mesh_volume(*ores)

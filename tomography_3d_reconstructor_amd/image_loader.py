@@ -86,10 +86,12 @@ class ImageLoader:
             setattr(self, "side_%d_count" % k, len(found))
         return files
 
-    # -- step 2: decode into ONE stack (page-locked when it is going to the GPU)
+    # -- step 2: decode into ONE stack
     def _decode_stack(self, files, on_gpu):
-        """-> (grey (n, H, W) uint8 ndarray, its backing pinned tensor or None, all decodes exact?) ; n may be 0."""
-        stack = backing = None
+        """-> (grey (n, H, W) uint8 ndarray, the same as a torch tensor when it is going to the GPU else None, all decodes
+        exact?) ; n may be 0.  (Ordinary memory: on this platform the upload is as fast from pageable memory as from
+        page-locked, and page-locking a stack costs ~65 ms per GiB -- _hostbuf.py.)"""
+        stack = None
         n, exact = 0, True
         for path in files:
             img, ok = _decode(path)
@@ -98,11 +100,7 @@ class ImageLoader:
             if stack is None:                               # the first readable image fixes the slice shape
                 self.image_height, self.image_width = img.shape
                 shape = (len(files),) + img.shape
-                if on_gpu:
-                    backing = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
-                    stack = backing.numpy()
-                else:
-                    stack = np.empty(shape, dtype=np.uint8)
+                stack = np.empty(shape, dtype=np.uint8)
             elif img.shape != stack.shape[1:]:
                 continue                                    # other shape: skipped
             stack[n] = img
@@ -110,7 +108,7 @@ class ImageLoader:
             n += 1
         if stack is None:
             return np.empty((0, 0, 0), np.uint8), None, True
-        return stack[:n], (backing[:n] if backing is not None else None), exact
+        return stack[:n], (torch.from_numpy(stack[:n]) if on_gpu else None), exact
 
     def load_mask_images(self, directory: str = ".", threshold: int = 200, load_sides: list = [True, True, True]) -> bool:
         """(:37-120) True when at least one mask was loaded."""
@@ -135,8 +133,8 @@ class ImageLoader:
                 try:
                     dev = torch.device("cuda", torch.cuda.current_device())
                     # integer grey levels: g >= t  <=>  g >= ceil(t)
-                    vol = pipeline.pack_threshold(backing.to(dev, non_blocking=True), math.ceil(threshold))
-                    torch.cuda.current_stream().synchronize()       # the pinned block may go once this returns
+                    vol = pipeline.pack_threshold(backing.to(dev), math.ceil(threshold))
+                    torch.cuda.current_stream().synchronize()
                     # write-protect the stack BEFORE the per-slice views exist: they inherit the flag, and the remembered
                     # device copy can then never differ from what the caller sees
                     _devcache.put(masks, vol)

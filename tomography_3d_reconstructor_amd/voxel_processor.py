@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-from . import _devcache, _memo, pipeline
+from . import _devcache, _hostbuf, _memo, pipeline
 
 
 def _device():
@@ -39,8 +39,22 @@ def upload_volume(voxel_data):
     return pipeline.pack(t)
 
 
+_NP_OF = {torch.bool: np.bool_, torch.uint8: np.uint8, torch.float32: np.float32, torch.int64: np.int64, torch.int32: np.int32}
+
+
+BIG = 1 << 28        # bytes from which a transfer goes straight from / into ordinary (pageable) memory: ROCm page-locks a large
+#                      pageable buffer on the fly (1 GiB: 21 ms against 19 ms page-locked), smaller ones pass through its staging
+#                      buffers at a fraction of the bus rate -- those use torch's page-locked cache (a few ms to lock, once)
+
+
 def to_host_array(t):
-    """Device tensor -> fresh host ndarray backed by page-locked memory (see to_host_volume)."""
+    """Device tensor -> fresh host ndarray.  Volume-sized results are ordinary NumPy arrays whose pages many threads have
+    brought in (_hostbuf: page-locking a fresh gibibyte costs ~65 ms, the first run of a process would pay it three times);
+    mesh-sized ones are NumPy views of page-locked torch tensors."""
+    if t.numel() * t.element_size() >= BIG:
+        out = _hostbuf.take(tuple(t.shape), _NP_OF[t.dtype])
+        torch.from_numpy(out).copy_(t)          # ordered after the current stream's work; returns when the bytes are there
+        return out
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
@@ -48,9 +62,7 @@ def to_host_array(t):
 
 
 def to_host_volume(vol):
-    """BitVolume -> fresh host bool ndarray.  The array lives in page-locked memory (it is the NumPy view of a pinned
-    torch tensor, which it keeps alive): the 1 B/voxel download runs at PCIe speed instead of through a pageable
-    bounce buffer, and the block goes back to torch's pinned-memory cache when the array is garbage collected."""
+    """BitVolume -> fresh host bool ndarray, remembered (write-protected) against its device copy."""
     out = to_host_array(pipeline.unpack(vol))
     _devcache.put(out, vol)
     return out
@@ -66,26 +78,35 @@ def _stage_masks(mask_images):
     if first.ndim != 2:
         raise ValueError("all input arrays must have the same shape")          # what np.stack reports for ragged input
     nz = len(mask_images)
-    stage = torch.empty((nz,) + first.shape, dtype=torch.bool, pin_memory=True)
-    dst = stage.numpy()
+    # np.stack into ONE staging array (ordinary memory: its pages are brought in by the copying workers themselves, in
+    # parallel), cut into chunks of slices; every chunk is uploaded as soon as its host copy is done, so the PCIe transfer
+    # runs under the host copies of the later chunks.  (Rounds 1-2 staged through page-locked memory: 68 ms of page-locking
+    # in front of the first call of a process, for a transfer that is as fast from pageable memory on this platform.)
+    workers = max(1, min(8, os.cpu_count() or 1, nz))
+    stage = np.empty((nz,) + first.shape, dtype=np.bool_)
+    # uploads in pieces of >= 128 MiB (below that ROCm stages a pageable source through its own buffers at a fraction of the
+    # bus rate; above it the source is page-locked on the fly: 1 GiB in 8 pieces 19 ms, in 32 pieces 90-120 ms), every piece
+    # filled by all workers in finer runs of slices
+    per_slice = max(first.size, 1)
+    up = max(1, min(nz, (128 << 20) // per_slice + (1 if (128 << 20) % per_slice else 0)))      # slices per upload piece
+    fine = max(1, -(-up // workers))                                                           # slices per worker task
 
-    def copy(lo, hi):
+    def fill(lo, hi):
         for i in range(lo, hi):
             m = np.asarray(mask_images[i])
             if m.shape != first.shape:
                 raise ValueError("all input arrays must have the same shape")
-            dst[i] = m if m.dtype == np.bool_ else (m != 0)
-    # the stack is cut into chunks of slices; every chunk is uploaded as soon as its host copy is done, so the PCIe
-    # transfer runs under the host copies of the later chunks (1 GiB: 29 ms -> the 19 ms the bus needs, plus one chunk)
-    workers = max(1, min(8, os.cpu_count() or 1, nz))
-    nchunks = max(1, min(nz, 4 * workers))
-    step = -(-nz // nchunks)
-    dev = torch.empty(stage.shape, dtype=torch.bool, device=_device())
+            stage[i] = m if m.dtype == np.bool_ else (m != 0)
+    dev = torch.empty((nz,) + first.shape, dtype=torch.bool, device=_device())
     with ThreadPoolExecutor(workers) as ex:
-        futs = [(lo, min(nz, lo + step), ex.submit(copy, lo, min(nz, lo + step))) for lo in range(0, nz, step)]
-        for lo, hi, fut in futs:
-            fut.result()
-            dev[lo:hi].copy_(stage[lo:hi], non_blocking=True)
+        pieces = []
+        for lo in range(0, nz, up):
+            hi = min(nz, lo + up)
+            pieces.append((lo, hi, [ex.submit(fill, a, min(hi, a + fine)) for a in range(lo, hi, fine)]))
+        for lo, hi, futs in pieces:
+            for fut in futs:
+                fut.result()
+            dev[lo:hi].copy_(torch.from_numpy(stage[lo:hi]))
     return dev.view(torch.uint8)
 
 
@@ -124,6 +145,10 @@ class VoxelProcessor:
         self.side_2_count = side_2_count
         base = _common_base(mask_images)
         cached = _devcache.get(base) if base is not None else None
+        if close_ends and torch.cuda.is_available():
+            # the 1 B/voxel host arrays this call and the smooth_voxel_data that follows it hand back: their pages are brought in
+            # NOW, on helper threads, next to the upload
+            _hostbuf.reserve(len(mask_images) * np.asarray(mask_images[0]).size, count=2)
         if cached is not None and not base.flags.writeable and any(m.flags.writeable for m in mask_images):
             # writeable views of a protected stack: its content may have changed behind the flag -- the remembered device
             # copy is dropped for good (a later lookup must not find it either) and the stack is uploaded again
