@@ -52,6 +52,8 @@ int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_
  * the 1 B/voxel arrays the drop-in classes hand back (voxel_processor.py:46, :84 create them with np.stack / .copy()) cost
  * ~65 ms per GiB of page faults when a single thread -- or the DMA engine's pinning pass -- touches them first. */
 int tomo_host_touch(void *h_data, int64_t nbytes, int nthreads);
+/* np.stack (voxel_processor.py:46) on `nthreads` threads: h_dst[i * bytes_each ..] = the bytes_each bytes at h_src[i]. */
+int tomo_host_gather(const void *const *h_src, int64_t n, int64_t bytes_each, void *h_dst, int nthreads);
 
 /* ---------------------------------------------------------------- geometry helpers (host, pure) */
 int64_t tomo_words_per_row(int nx);                      /* ceil(nx / 64) */

@@ -27,6 +27,7 @@ SIGNATURES = {
     "tomo_host_mc_centre_offset": (None, [_c_p, _c_p]),
     "tomo_host_checksum": (_c_i, [_c_p, _c_i64, _c_i, _c_p]),
     "tomo_host_touch": (_c_i, [_c_p, _c_i64, _c_i]),
+    "tomo_host_gather": (_c_i, [_c_p, _c_i64, _c_i64, _c_p, _c_i]),
     "tomo_words_per_row": (_c_i64, [_c_i]),
     "tomo_ext_words_per_row": (_c_i64, [_c_i, _c_i]),
     "tomo_ext_rows": (_c_i64, [_c_i, _c_i]),

@@ -138,3 +138,38 @@ TOMO_API int tomo_host_touch(void *h_data, int64_t nbytes, int nthreads)
     p[nbytes - 1] = 0;
     return TOMO_OK;
 }
+
+// np.stack on several threads: h_dst[i * bytes_each ...] = the bytes of h_src[i], i = 0 .. n-1 (n separate host buffers of
+// bytes_each bytes -- the reference stacks its mask images with np.stack, voxel_processor.py:46, one thread, 85 ms for 1024
+// masks of 1 MiB on the MI355X host).  The destination may be fresh memory: every thread brings the pages of its own share in.
+TOMO_API int tomo_host_gather(const void *const *h_src, int64_t n, int64_t bytes_each, void *h_dst, int nthreads)
+{
+    if (n < 0 || bytes_each < 0 || (n > 0 && bytes_each > 0 && (!h_src || !h_dst))) return TOMO_E_ARG;
+    if (n == 0 || bytes_each == 0) return TOMO_OK;
+    for (int64_t i = 0; i < n; i++) if (!h_src[i]) return TOMO_E_ARG;
+    uint8_t *dst = (uint8_t *)h_dst;
+    // the work is cut into pieces of <= 1 MiB, dealt out contiguously: a thread writes one contiguous run of the destination
+    const int64_t PIECE = 1 << 20;
+    const int64_t per_src = (bytes_each + PIECE - 1) / PIECE, pieces = n * per_src;
+    if (nthreads < 1) nthreads = 1;
+    if ((int64_t)nthreads > pieces) nthreads = (int)pieces;
+    auto work = [&](int64_t a, int64_t b) {
+        for (int64_t q = a; q < b; q++) {
+            const int64_t i = q / per_src, off = (q - i * per_src) * PIECE;
+            const int64_t len = bytes_each - off < PIECE ? bytes_each - off : PIECE;
+            memcpy(dst + i * bytes_each + off, (const uint8_t *)h_src[i] + off, (size_t)len);
+        }
+    };
+    if (nthreads == 1) {
+        work(0, pieces);
+    } else {
+        std::vector<std::thread> th;
+        const int64_t per = (pieces + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; t++) {
+            const int64_t a = t * per, b = a + per < pieces ? a + per : pieces;
+            if (a < b) th.emplace_back(work, a, b);
+        }
+        for (auto &t : th) t.join();
+    }
+    return TOMO_OK;
+}

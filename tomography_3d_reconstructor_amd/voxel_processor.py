@@ -82,13 +82,37 @@ def _stage_masks(mask_images):
     # parallel), cut into chunks of slices; every chunk is uploaded as soon as its host copy is done, so the PCIe transfer
     # runs under the host copies of the later chunks.  (Rounds 1-2 staged through page-locked memory: 68 ms of page-locking
     # in front of the first call of a process, for a transfer that is as fast from pageable memory on this platform.)
-    workers = max(1, min(8, os.cpu_count() or 1, nz))
     stage = np.empty((nz,) + first.shape, dtype=np.bool_)
     # uploads in pieces of >= 128 MiB (below that ROCm stages a pageable source through its own buffers at a fraction of the
-    # bus rate; above it the source is page-locked on the fly: 1 GiB in 8 pieces 19 ms, in 32 pieces 90-120 ms), every piece
-    # filled by all workers in finer runs of slices
+    # bus rate; above it the source is page-locked on the fly: 1 GiB in 8 pieces 19 ms, in 32 pieces 90-120 ms)
     per_slice = max(first.size, 1)
-    up = max(1, min(nz, (128 << 20) // per_slice + (1 if (128 << 20) % per_slice else 0)))      # slices per upload piece
+    up = max(1, min(nz, -(-(128 << 20) // per_slice)))                                           # slices per upload piece
+    dev = torch.empty((nz,) + first.shape, dtype=torch.bool, device=_device())
+    # Fast path (what an image loader produces: separate C-contiguous bool / uint8-of-0/1... arrays of one shape): the
+    # stacking is a native multi-threaded gather (tomo_host_gather) -- piece k + 1 is gathered on a helper thread while
+    # piece k is on the bus.  (Python worker threads copying slice by slice took 17-60 ms for the same gibibyte, at the
+    # mercy of the interpreter lock; np.stack itself 85 ms.)
+    L = pipeline._lib.lib()
+    ptrs = np.empty(nz, dtype=np.uintp)
+    plain = True
+    for i, m in enumerate(mask_images):
+        if not (isinstance(m, np.ndarray) and m.dtype == np.bool_ and m.shape == first.shape and m.flags.c_contiguous):
+            plain = False
+            break
+        ptrs[i] = m.__array_interface__["data"][0]
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    if plain:
+        def gather(lo, hi):
+            pipeline._lib.check(L.tomo_host_gather(ptrs[lo:hi].ctypes.data, hi - lo, per_slice, stage[lo:hi].ctypes.data, nthreads),
+                                "tomo_host_gather")
+        with ThreadPoolExecutor(1) as ex:
+            spans = [(lo, min(nz, lo + up)) for lo in range(0, nz, up)]
+            futs = [ex.submit(gather, lo, hi) for lo, hi in spans]
+            for (lo, hi), fut in zip(spans, futs):
+                fut.result()
+                dev[lo:hi].copy_(torch.from_numpy(stage[lo:hi]))
+        return dev.view(torch.uint8)
+    workers = max(1, min(8, os.cpu_count() or 1, nz))
     fine = max(1, -(-up // workers))                                                           # slices per worker task
 
     def fill(lo, hi):
@@ -97,7 +121,6 @@ def _stage_masks(mask_images):
             if m.shape != first.shape:
                 raise ValueError("all input arrays must have the same shape")
             stage[i] = m if m.dtype == np.bool_ else (m != 0)
-    dev = torch.empty((nz,) + first.shape, dtype=torch.bool, device=_device())
     with ThreadPoolExecutor(workers) as ex:
         pieces = []
         for lo in range(0, nz, up):

@@ -26,6 +26,15 @@ for nm in ("pack_closed", "smooth", "extract_surface", "unpack"):
 wrap(_hostbuf, "take", sync=False)
 import tomography_3d_reconstructor_amd.surface_extractor as SE
 SE.to_host_array = VP.to_host_array
+if os.environ.get("NO_RESERVE"):
+    _hostbuf.reserve = lambda *a, **k: None
+if os.environ.get("INNER"):
+    import concurrent.futures as cf
+    orig_copy = torch.Tensor.copy_
+    tacc = {"copy": 0.0, "n": 0}
+    def timed_copy(self, src, *a, **k):
+        t0 = time.perf_counter(); r = orig_copy(self, src, *a, **k); tacc["copy"] += (time.perf_counter() - t0) * 1e3; tacc["n"] += 1; return r
+    torch.Tensor.copy_ = timed_copy
 for run in range(3):
     acc.clear()
     vp, se = VoxelProcessor(), SurfaceExtractor()
@@ -37,4 +46,6 @@ for run in range(3):
         res = se.extract_manifold_surface(sm, depths, 1.0, 1.0, smooth=True, manifold=True, add_padding=True); t3 = time.perf_counter()
     print("run %d: total %.1f ms = create %.1f + smooth %.1f + extract %.1f | %s" % (
         run, (t3 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, ", ".join("%s %.1f" % kv for kv in sorted(acc.items()))), flush=True)
+    if os.environ.get("INNER"):
+        print("   copy_ calls: %d, %.1f ms in total" % (tacc["n"], tacc["copy"])); tacc["copy"] = 0.0; tacc["n"] = 0
     t0 = time.perf_counter(); del vol, sm, res; print("   (freeing the results: %.1f ms)" % ((time.perf_counter() - t0) * 1e3))
