@@ -264,3 +264,73 @@ def test_merged_front_with_a_misaligned_mask_on_one_rank(dev):
     [t.join(120) for t in ts]
     assert not errs, errs
     check_pass(out, ref)
+
+
+def run_pipelined(world, volumes, depths, mm_y, mm_x, dev):
+    """run_passes with the host reading every pass ONE PASS LATE: submit(k + 1) before result(k) (what bench.py does)."""
+    nz, ny, nx = volumes[0].shape
+    out = [[None] * world for _ in volumes]
+    stats, errs = [None] * world, []
+
+    def target(c):
+        try:
+            job = slab.SlabJob(nz, ny, nx, c)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                masks = [torch.from_numpy(np.ascontiguousarray(v[job.z0:job.z1]).view(np.uint8)).to(dev) for v in volumes]
+                pend = None
+                for p in range(len(volumes) + 1):
+                    nxt = job.submit(masks[p], depths, mm_y, mm_x) if p < len(volumes) else None
+                    if pend is not None:
+                        verts, faces = job.result(pend)
+                        assert job.mesh[0] is verts and job.smoothed is not None
+                        out[p - 1][c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.vertex_offset, job.n_vertices_global)
+                    pend = nxt
+                torch.cuda.current_stream().synchronize()
+            stats[c.rank] = (job.deferred_passes, job.deferred_redone)
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            raise
+
+    ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    return out, stats
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_submit_before_result_gives_the_same_meshes(dev, world):
+    """SlabJob.submit / result: pass k + 1 is enqueued BEFORE the host reads the counters of pass k.  Stacks that differ from
+    pass to pass (so a stale buffer or a result published under the wrong pass would show), incl. one that outgrows the
+    hints while the next pass is already in flight: every pass equals the single-GPU mesh of ITS stack, the numbering
+    (vertex_offset / n_vertices_global) belongs to the pass that result() returned."""
+    if not (pipeline.MC3 and pipeline.NA_HINTS and slab.DEFERRED_NUMBERING):
+        pytest.skip("needs the mc3 chain with size hints")
+    nz, ny, nx = 128, 96, 144
+    a, b, big = blob(nz, ny, nx, 0.8, 1), blob(nz, ny, nx, 0.8, 2), blob(nz, ny, nx, 1.0, 3)
+    volumes = [a, a, b, a, big, b, b]
+    depths = np.concatenate([np.full(40, 0.5), np.full(48, 0.25), np.full(40, 0.75)])
+    refs = {id(v): single_gpu(v, depths, 0.7, 0.9, dev) for v in (a, b, big)}
+    out, stats = run_pipelined(world, volumes, depths, 0.7, 0.9, dev)
+    for per_rank, v in zip(out, volumes):
+        check_pass(per_rank, refs[id(v)])
+    assert all(s == stats[0] for s in stats) and stats[0][0] >= 3, stats       # deferred passes happened, alike on every rank
+
+
+def test_extract_surface_submit_reads_one_pass_late(dev):
+    """pipeline.extract_surface_submit: the single-GPU counterpart -- two surfaces in flight, results read in order, each
+    equal to the plain call on its own volume; None where the reference returns None."""
+    nz, ny, nx = 96, 80, 112
+    vols = [blob(nz, ny, nx, s, k) for k, s in enumerate((0.7, 1.0, 0.7, 0.9))] + [np.zeros((nz, ny, nx), bool)]
+    depths = np.full(nz, 0.6)
+    dv = [pipeline.smooth(pipeline.close_ends(pipeline.pack(torch.from_numpy(v.view(np.uint8)).to(dev))), 3, True) for v in vols]
+    plain = [pipeline.extract_surface(x, depths, 0.7, 0.9) for x in dv]
+    got, pend = [], None
+    for x in dv + [None]:
+        nxt = pipeline.extract_surface_submit(x, depths, 0.7, 0.9) if x is not None else None
+        if pend is not None:
+            got.append(pend.result())
+        pend = nxt
+    assert plain[-1] is None and got[-1] is None
+    for p, g in zip(plain[:-1], got[:-1]):
+        assert torch.equal(p[0], g[0]) and torch.equal(p[1], g[1])

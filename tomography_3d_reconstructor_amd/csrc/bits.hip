@@ -1357,6 +1357,9 @@ __device__ static inline u32 fw_op3(int OP, u32 a, u32 b, u32 c)
 // [w0 - 2, w0 + 6) words is one 64-byte piece of a line -- and a wave-private LDS image turns that into lane = row and
 // back (80- and 48-byte row pitches: conflict-free 16-byte LDS accesses).  Needs even wx and 16-byte aligned volumes;
 // everything else takes the direct path (STAGED = false).
+#ifndef FW_DPP_FUSE
+#define FW_DPP_FUSE 1
+#endif
 template <int H, int OPS, bool STAGED>
 __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int nz, int ny,
                                                               int nx, int wx, int zchunk, int nxt, int nyt, int64_t nwaves)
@@ -1512,8 +1515,21 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
                         const u32 yl1 = (u32)__builtin_amdgcn_mov_dpp((int)chi, 0x138, 0xf, 0xf, true);
                         const u32 yh0 = (u32)__builtin_amdgcn_mov_dpp((int)clo, 0x130, 0xf, 0xf, true);
                         const u32 yh1 = (u32)__builtin_amdgcn_mov_dpp((int)chi, 0x130, 0xf, 0xf, true);
+#if FW_DPP_FUSE
+                        // c op row-above op row-below as TWO 2-input ops that each take their shifted operand through DPP
+                        // (v_and_b32_dpp / v_or_b32_dpp: the compiler folds the v_mov_b32_dpp into a VOP2 consumer, never
+                        // into the VOP3 v_bitop3_b32) -- 8 instead of 9 VALU ops per half and pass.  The empty asm keeps the
+                        // two ops from being re-fused into one 3-input bitop3 with two separate DPP moves.
+                        u32 a0 = OP == 0 ? (clo & yl0) : (clo | yl0), a1 = OP == 0 ? (chi & yl1) : (chi | yl1);
+                        asm("" : "+v"(a0), "+v"(a1));
+                        u32 b0 = OP == 0 ? (a0 & yh0) : (a0 | yh0), b1 = OP == 0 ? (a1 & yh1) : (a1 | yh1);
+                        asm("" : "+v"(b0), "+v"(b1));
+                        Q[j][k][0] = fw_out(OP, fw_op3(OP, b0, xl0, xh0), X[p ^ 1][j][k][0], zp);
+                        Q[j][k][1] = fw_out(OP, fw_op3(OP, b1, xl1, xh1), X[p ^ 1][j][k][1], zp);
+#else
                         Q[j][k][0] = fw_out(OP, fw_op3(OP, fw_op3(OP, clo, yl0, yh0), xl0, xh0), X[p ^ 1][j][k][0], zp);
                         Q[j][k][1] = fw_out(OP, fw_op3(OP, fw_op3(OP, chi, yl1, yh1), xl1, xh1), X[p ^ 1][j][k][1], zp);
+#endif
                     }
                     if (j == 0) {
                         // The slice finished in the previous iteration is stored here, before the next loads are issued
