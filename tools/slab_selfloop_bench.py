@@ -7,7 +7,8 @@ real world-size-1 `nccl` process group -- the same batched isend / irecv of uint
 uses, enqueued on the same streams.  What arrives "from below" is what was sent "up" (and vice versa), so the halo
 content is not that of a real stack (the mesh has a seam and is not checked); sizes, kernels, launches, host round trips
 and the RCCL calls are those of a middle rank.  What is missing is the time on the xGMI link (3 MB per pass).
-usage: slab_selfloop_bench.py [slices_per_rank] [ny] [nx] [steps]"""
+usage: slab_selfloop_bench.py [slices_per_rank] [ny] [nx] [steps] [world=3] [rank=world//2]
+(BASELINE configs[4] per rank: 512 2048 2048 10 8 3 -- slab 3 of the 8 slabs of the 2048 x 2048 x 4096 stack)"""
 import datetime
 import os
 import sys
@@ -72,7 +73,7 @@ class SelfLoopRccl:
     """The same play on rccl.RcclComm (RCCL's C API on the compute stream): logical rank 1 of 3, every peer is rank 0 of the
     1-rank communicator."""
 
-    def __new__(cls, device):
+    def __new__(cls, device, rank=1, world=3):
         from tomography_3d_reconstructor_amd import rccl
 
         class _Loop(rccl.RcclComm):
@@ -93,7 +94,7 @@ class SelfLoopRccl:
 
         c = _Loop(device)
         c._real_world = c.world
-        c.rank, c.world = 1, 3
+        c.rank, c.world = rank, world
         return c
 
 
@@ -102,14 +103,16 @@ def main():
     ny = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     nx = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    world = int(sys.argv[5]) if len(sys.argv) > 5 else 3          # the pretend job: `world` slabs of nzr slices, this process plays
+    rank = int(sys.argv[6]) if len(sys.argv) > 6 else world // 2  # slab `rank` (a middle one)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29618")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     td.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
     direct = os.environ.get("TOMO_RCCL_DIRECT", "1") not in ("", "0")
-    comm = SelfLoopRccl(dev) if direct else SelfLoopComm(dev)
-    gz = 3 * nzr
+    comm = SelfLoopRccl(dev, rank, world) if direct else SelfLoopComm(dev, rank, world)
+    gz = world * nzr
     job = slab.SlabJob(gz, ny, nx, comm)
     mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
     depths = np.full(gz, 1.0)
@@ -148,27 +151,6 @@ def main():
         job.result(t)
     torch.cuda.synchronize()
     del tickets
-    # the single-GPU pass on the SAME slices (this rank's own mask stack as a stack of its own: same geometry, same surface
-    # density per slice; its end slices are not empty, so close-ends fills them -- a little more work than the slab's)
-    pend = None
-    for it in range(steps + 3):
-        if it == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        nxt = pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(nzr, 1.0), 1.0, 1.0)
-        if pend is not None:
-            pend.result()
-        pend = nxt
-    pend.result()
-    torch.cuda.synchronize()
-    same_ms = (time.perf_counter() - t0) / steps * 1e3
-    torch.cuda.synchronize()
-    h0 = time.perf_counter()
-    pends = [pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(nzr, 1.0), 1.0, 1.0) for _ in range(4)]
-    enq1_ms = (time.perf_counter() - h0) / 4 * 1e3
-    for q in pends:
-        q.result()
-    del pends, pend, nxt
     # the single-GPU pass on a stack of the slab's size, same box
     m1 = pipeline.ellipsoid_mask(nzr, ny, nx, dev).view(torch.uint8)
     d1 = np.full(nzr, 1.0)
@@ -188,12 +170,19 @@ def main():
         pend.result()
     torch.cuda.synchronize()
     one_ms = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    pends = [pipeline.extract_surface_submit(pipeline.smooth(pipeline.pack_closed(m1), 3, True), d1, 1.0, 1.0) for _ in range(4)]
+    enq1_ms = (time.perf_counter() - h0) / 4 * 1e3
+    for q in pends:
+        q.result()
+    del pends
     how = "RCCL communicator (C API, compute stream)" if direct else "nccl group (torch.distributed)"
-    print(("middle rank of %d x (%d, %d, %d), messages to self over a 1-rank " + how + ": %.3f ms per pass "
+    print(("rank %d of %d x (%d, %d, %d), messages to self over a 1-rank " + how + ": %.3f ms per pass "
            "(%d deferred, %d redone; %.1f RCCL calls and %.0f KB sent per pass, %.3f ms of host time inside them, "
            "%.3f ms of host time per pass in run()); %d vertices, %d faces kept; single-GPU pass on a slab-sized ellipsoid "
-           "stack: %.3f ms; single-GPU pass on THIS rank's own slices: %.3f ms; host time to enqueue a pass: slab %.3f ms, single %.3f ms") % (comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
-                                st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms, same_ms, enq_ms, enq1_ms),
+           "stack: %.3f ms; host time to enqueue a pass: slab %.3f ms, single %.3f ms") % (comm.rank, comm.world, nzr, ny, nx, slab_ms, job.deferred_passes, job.deferred_redone, st["calls"] / steps,
+                                st["bytes_sent"] / steps / 1e3, st["seconds"] / steps * 1e3, host / steps * 1e3, nv, nf, one_ms, enq_ms, enq1_ms),
           flush=True)
     if hasattr(comm, "close"):
         comm.close()
