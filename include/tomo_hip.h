@@ -245,7 +245,7 @@ int tomo_mc_first_touch(const float *field, int Nz, int Ny, int Nx, int64_t pitc
  *   tomo_mc3_eval      one float64 evaluation per active voxel: MC33 tiling reference, vertex flags, vertex coordinates
  *                      along the owned edges (float32), counts reduced per block of 256 entries
  *   tomo_mc3_scan      single workgroup: block prefixes, totals (tot[1] vertices, tot[2] triangles), per-slice tables and
- *                      the 2 Nz + 1 bucket offsets of the sort (slice_tab: tomo_mc3_slice_table_words(Nz) uint32)
+ *                      the offsets of the sort's segments (slice_tab: tomo_mc3_slice_table_words(Nz, Ny) uint32)
  *   tomo_mc3_vertices  FINAL vertex rows (-1 shift, slice-depth map, y / x scale: surface_extractor.py:57-65, :82-113) as
  *                      16-byte records {z', y', x', id}, partitioned per slice into in-plane / between-plane buckets,
  *                      with their 32-bit sort keys; vertex id = 4 * (list position of the owner voxel) + slot
@@ -266,7 +266,8 @@ int tomo_mc3_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int
                   const unsigned long long *vox_key, int64_t cap, const unsigned long long *tot, int z_offset,
                   uint32_t *vox_loc, int32_t *vox_til, uint8_t *vox_flags, uint16_t *vox_used, float *vox_f3, float *vox_c3,
                   uint32_t *blk3, void *stream);
-int64_t tomo_mc3_slice_table_words(int Nz);
+int64_t tomo_mc3_slice_table_words(int Nz, int Ny);
+int64_t tomo_mc3_sort_segments(int Nz, int Ny);      /* sort segments: per slice ceil(Ny / 32) bands of owner rows of the plane + the between-plane bucket */
 int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const uint32_t *vox_loc, int64_t cap,
                   uint32_t *blk3, uint32_t *slice_tab, unsigned long long *tot, int64_t cap_v, int64_t cap_f, void *stream);
 int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,
@@ -274,12 +275,12 @@ int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned long long
                       const float *vox_c3, const uint32_t *blk3, const uint32_t *slice_tab, int z_offset, int shift,
                       const double *cum, int64_t ncum, const double *adj, int64_t nadj, float mm_y, float mm_x, float *vrec,
                       uint32_t *keys, uint32_t *idx, void *stream);
-int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v);
-int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v, int64_t nseg);    /* nseg = tomo_mc3_sort_segments(Nz, Ny) */
+int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, int Ny, const uint32_t *slice_tab,
                        unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
                        void *stream);
 /* The same, and tot[7] = number of rows with z' == z_top (the plane a Z-slab rank shares with the rank above; NaN: none). */
-int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, int Ny, const uint32_t *slice_tab,
                            unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
                            float z_top, void *stream);
 int tomo_mc3_faces(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap, unsigned long long *tot,

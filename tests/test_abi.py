@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.tomo_abi_version() == 4
+    assert L.tomo_abi_version() == 5
     assert L.tomo_error_string(0) == b"ok"
     assert b"argument" in L.tomo_error_string(-1)
 

@@ -83,13 +83,14 @@ SIGNATURES = {
     "tomo_mc3_list": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "tomo_mc3_eval": (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_i64, _c_i, _c_d, _c_p, _c_i64, _c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p,
                              _c_p, _c_p, _c_p]),
-    "tomo_mc3_slice_table_words": (_c_i64, [_c_i]),
+    "tomo_mc3_slice_table_words": (_c_i64, [_c_i, _c_i]),
+    "tomo_mc3_sort_segments": (_c_i64, [_c_i, _c_i]),
     "tomo_mc3_scan": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "tomo_mc3_vertices": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i,
                                  _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p, _c_p, _c_p, _c_p]),
-    "tomo_mc3_sort_workspace_bytes": (_c_i64, [_c_i64]),
-    "tomo_mc3_sort_rank": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
-    "tomo_mc3_sort_rank_top": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_p]),
+    "tomo_mc3_sort_workspace_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tomo_mc3_sort_rank": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "tomo_mc3_sort_rank_top": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_p]),
     "tomo_mc3_faces": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),

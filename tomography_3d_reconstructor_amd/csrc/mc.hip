@@ -1027,8 +1027,14 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_eval_kernel(const float *__restri
     }
 }
 
-// ---- scan: block sums -> exclusive prefixes, totals, the per-slice tables and the 2 Nz + 1 bucket offsets of the sort.
-// slice_tab: sliceA[Nz + 1] | sliceB[Nz + 1] | offsets[2 Nz + 1]  (uint32)
+// ---- scan: block sums -> exclusive prefixes, totals and the per-slice tables; mc3_bands_kernel then writes the offsets of the
+// sort's segments.  slice_tab: sliceA[Nz + 1] | sliceB[Nz + 1] | offsets[(NB + 1) Nz + 1] | merge3[3]  (uint32), NB =
+// TOMO_SORT_NB(Ny): per slice NB bands of TOMO_SORT_BAND owner rows of in-plane vertices, then the between-plane vertices.
+// In a plane the vertices arrive grouped by owner row and a vertex of owner row Y has its key y' in [Y, Y + 1] * mm_y, so the
+// sort is local to a row -- a fortiori to a band of rows: ~100 entries per segment instead of 3 400 (1024^2 slices) or 6 700
+// (2048^2: beyond what the segmented sort keeps in LDS -- 922 us for 3.7 M vertices on a middle rank of BASELINE configs[4],
+// profiles/r03_slab_selfloop.md).  The between-plane keys z' are in no order: those buckets stay whole.
+// merge3 = {start of slab 0's between-plane bucket, start of slab 1's plane, its end}: the two runs uq3_merge_kernel merges.
 __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
                                                         const u32 *__restrict__ vox_loc, int64_t cap, u32 *__restrict__ blk3,
                                                         int64_t nblk, u32 *__restrict__ slice_tab, u64 *__restrict__ tot,
@@ -1041,7 +1047,7 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
     const u64 totA64 = totals[0], totB64 = totals[1], totT64 = totals[2];
     const u32 totA = (u32)totA64, totB = (u32)totB64;
     const int Nz = g.Nz;
-    u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1), *offsets = slice_tab + 2 * (Nz + 1);
+    u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1);
     const int64_t segs_per_slice = (int64_t)g.Ny * g.segs_per_row;
     const bool fits = na <= (u64)cap;
     for (int Z = threadIdx.x; Z <= Nz; Z += 1024) {
@@ -1057,21 +1063,51 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
         sliceA[Z] = a;
         sliceB[Z] = b;
     }
-    __syncthreads();
     u64 ov = 0;
     if (totA64 + totB64 > (u64)cap_v) ov |= 2ull;
     if (totT64 > (u64)cap_f) ov |= 4ull;
     if (!fits) ov |= 1ull;
-    for (int Z = threadIdx.x; Z < Nz; Z += 1024) {           // on overflow every bucket is empty: the sort touches nothing
-        offsets[2 * Z] = ov ? 0u : sliceA[Z] + sliceB[Z];
-        offsets[2 * Z + 1] = ov ? 0u : sliceA[Z + 1] + sliceB[Z];
-    }
     if (threadIdx.x == 0) {
-        offsets[2 * Nz] = ov ? 0u : totA + totB;
         tot[1] = totA64 + totB64;
         tot[2] = totT64;
         if (ov) atomicOr((unsigned long long *)&tot[3], (unsigned long long)ov);
     }
+}
+
+// one thread per sort segment (Z, b): b < NB the band of owner rows [b, b + 1) * TOMO_SORT_BAND of plane Z, b == NB the
+// between-plane bucket; on overflow (tot[3]) every segment is empty: the sort touches nothing
+__global__ __launch_bounds__(256) void mc3_bands_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
+                                                        const u32 *__restrict__ vox_loc, const u32 *__restrict__ blk3,
+                                                        int64_t nblk, u32 *__restrict__ slice_tab, const u64 *__restrict__ tot)
+{
+    const int Nz = g.Nz, NB = TOMO_SORT_NB(g.Ny);
+    const int64_t nseg = (int64_t)(NB + 1) * Nz, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1);
+    u32 *offsets = slice_tab + 2 * (Nz + 1), *merge3 = offsets + nseg + 1;
+    const bool ov = tot[3] != 0;
+    const u64 na = tot[0];
+    if (i == nseg) {
+        offsets[nseg] = ov ? 0u : sliceA[Nz] + sliceB[Nz];
+        // slab 0's between-plane bucket and slab 1's plane (uq3_merge_kernel; Nz >= 2 always)
+        merge3[0] = ov ? 0u : sliceA[1] + sliceB[0];
+        merge3[1] = ov ? 0u : sliceA[1] + sliceB[1];
+        merge3[2] = ov ? 0u : sliceA[Nz >= 2 ? 2 : 1] + sliceB[1];
+        return;
+    }
+    if (i > nseg) return;
+    const int Z = (int)(i / (NB + 1)), b = (int)(i - (int64_t)Z * (NB + 1));
+    u32 o = 0u;
+    if (!ov) {
+        if (b == NB) {
+            o = sliceA[Z + 1] + sliceB[Z];
+        } else {
+            // in-plane vertices before the first voxel of row (Z, b * BAND): the list position of that voxel, then its prefix
+            const u64 s = seg_aoff[((int64_t)Z * g.Ny + (int64_t)b * TOMO_SORT_BAND) * g.segs_per_row];
+            const u32 a = s < na ? blk3[s >> 8] + MC3_LOC_A(vox_loc[s]) : sliceA[Nz];
+            o = a + sliceB[Z];
+        }
+    }
+    offsets[i] = o;
 }
 
 // ---- vertices: final coordinates (surface_extractor.py:57-65, :82-113 -- the arithmetic of vertex_finalize_kernel),
@@ -1294,7 +1330,8 @@ TOMO_API int tomo_mc3_eval(const float *field, int Nz, int Ny, int Nx, int64_t p
     return tomo_status();
 }
 
-TOMO_API int64_t tomo_mc3_slice_table_words(int Nz) { return 4 * (int64_t)Nz + 8; }
+TOMO_API int64_t tomo_mc3_sort_segments(int Nz, int Ny) { return (int64_t)(TOMO_SORT_NB(Ny) + 1) * Nz; }
+TOMO_API int64_t tomo_mc3_slice_table_words(int Nz, int Ny) { return 2 * ((int64_t)Nz + 1) + tomo_mc3_sort_segments(Nz, Ny) + 1 + 3 + 8; }
 
 TOMO_API int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const uint32_t *vox_loc, int64_t cap,
                            uint32_t *blk3, uint32_t *slice_tab, unsigned long long *tot, int64_t cap_v, int64_t cap_f,
@@ -1306,6 +1343,10 @@ TOMO_API int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
     hipLaunchKernelGGL(mc3_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, seg_aoff, vox_loc, cap, blk3,
                        ceil_div64(cap, MC3_BLK), slice_tab, (u64 *)tot, cap_v, cap_f);
+    const int64_t nseg = tomo_mc3_sort_segments(Nz, Ny);
+    if (nseg + 1 > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc3_bands_kernel, dim3((unsigned)ceil_div64(nseg + 1, 256)), dim3(256), 0, (hipStream_t)stream, g, seg_aoff,
+                       vox_loc, (const u32 *)blk3, ceil_div64(cap, MC3_BLK), slice_tab, (const u64 *)tot);
     return tomo_status();
 }
 

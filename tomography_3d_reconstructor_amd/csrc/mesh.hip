@@ -276,6 +276,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 typedef rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<512, 8>, rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>, true>
     UqSegCfg;
 
+
 static UqLayout uq_layout(int64_t nv)
 {
     UqLayout L;
@@ -413,8 +414,8 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
 
 // ------------------------------------------------------------------------------------------ mc3: sort + rank
 // The unique stage of the mc3 chain (mc.hip): vertices arrive FINALISED as 16-byte records {z', y', x', id}, already
-// partitioned into the 2 Nz buckets (offsets from mc3_scan_kernel) with their 32-bit sort keys.  One segmented sort
-// inside the buckets, the clamped-run merge of the first two buckets (see uq_merge_kernel), and one gather that writes
+// partitioned into the 2 Nz buckets with their 32-bit sort keys; the offsets (mc3_bands_kernel) cut every plane's bucket
+// further into bands of owner rows -- the order inside a plane is local to a row.  One segmented sort inside the segments, the clamped-run merge of the first two buckets (see uq_merge_kernel), and one gather that writes
 // the rows in order, table[id] = position, and counts every place where the result does not ascend STRICTLY: with a
 // count of zero the sorted position is np.unique's index (no duplicate rows, no rounding coincidence) -- otherwise the
 // caller redoes the stage with tomo_mesh_unique on the rows.
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void uq3_rank_kernel(const float4 *__restrict_
 
 struct Uq3Layout { size_t keys_alt, idx_alt, idx_merge, temp, temp_bytes, total; };
 
-static Uq3Layout uq3_layout(int64_t cap_v)
+static Uq3Layout uq3_layout(int64_t cap_v, int64_t nseg)
 {
     Uq3Layout L;
     size_t n = (size_t)(cap_v > 0 ? cap_v : 1), off = 0;
@@ -493,7 +494,7 @@ static Uq3Layout uq3_layout(int64_t cap_v)
     L.keys_alt = take(n * 4); L.idx_alt = take(n * 4); L.idx_merge = take(n * 4);
     size_t t = 0;
     (void)rocprim::segmented_radix_sort_pairs<UqSegCfg>(nullptr, t, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u32 *)nullptr,
-                                                        (unsigned)n, (unsigned)(2 * UQ_MAX_SLABS), (const u32 *)nullptr,
+                                                        (unsigned)n, (unsigned)(nseg > 0 ? nseg : 1), (const u32 *)nullptr,
                                                         (const u32 *)nullptr, 0, 32, (hipStream_t)0);
     L.temp_bytes = t;
     L.temp = take(t + 256);
@@ -501,40 +502,44 @@ static Uq3Layout uq3_layout(int64_t cap_v)
     return L;
 }
 
-TOMO_API int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v) { return (int64_t)uq3_layout(cap_v).total; }
+TOMO_API int64_t tomo_mc3_sort_workspace_bytes(int64_t cap_v, int64_t nseg) { return (int64_t)uq3_layout(cap_v, nseg).total; }
 
-TOMO_API int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
-                                    unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
-                                    float z_top, void *stream)
+TOMO_API int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, int Ny,
+                                    const uint32_t *slice_tab, unsigned long long *tot, float *uniq, int32_t *table, void *workspace,
+                                    int64_t workspace_bytes, float z_top, void *stream)
 {
-    if (!vrec || !keys || !idx || !slice_tab || !tot || !uniq || !table || !workspace || cap_v <= 0 || Nz < 1) return TOMO_E_ARG;
+    if (!vrec || !keys || !idx || !slice_tab || !tot || !uniq || !table || !workspace || cap_v <= 0 || Nz < 1 || Ny < 1) return TOMO_E_ARG;
     if (cap_v >= 0x7fffffffll || Nz > UQ_MAX_SLABS) return TOMO_E_SIZE;
-    Uq3Layout L = uq3_layout(cap_v);
+    // segments: per slice TOMO_SORT_NB(Ny) bands of owner rows of the plane, then the between-plane bucket (mc3_bands_kernel)
+    const int64_t nseg = (int64_t)(TOMO_SORT_NB(Ny) + 1) * Nz;
+    if (nseg >= 0x7fffffffll) return TOMO_E_SIZE;
+    Uq3Layout L = uq3_layout(cap_v, nseg);
     if ((size_t)workspace_bytes < L.total) return TOMO_E_WORKSPACE;
     char *ws = (char *)workspace;
     u32 *keys_alt = (u32 *)(ws + L.keys_alt), *idx_alt = (u32 *)(ws + L.idx_alt), *idx_merge = (u32 *)(ws + L.idx_merge);
     const u32 *offsets = slice_tab + 2 * ((int64_t)Nz + 1);
+    const u32 *merge3 = offsets + nseg + 1;
     hipStream_t s = (hipStream_t)stream;
     size_t tb = L.temp_bytes;
-    if (rocprim::segmented_radix_sort_pairs<UqSegCfg>(ws + L.temp, tb, keys, keys_alt, idx, idx_alt, (unsigned)cap_v, (unsigned)(2 * Nz),
+    if (rocprim::segmented_radix_sort_pairs<UqSegCfg>(ws + L.temp, tb, keys, keys_alt, idx, idx_alt, (unsigned)cap_v, (unsigned)nseg,
                                                       offsets, offsets + 1, 0, 32, s) != hipSuccess)
         return TOMO_E_LAUNCH;
     UqOrder order{(const u32 *)idx_alt, nullptr, nullptr};
-    if (Nz >= 2) {
-        hipLaunchKernelGGL(uq3_merge_kernel, dim3(256), dim3(256), 0, s, (const float4 *)vrec, offsets, (const u32 *)idx_alt, idx_merge);
+    if (Nz >= 2) {                                  // (UqOrder and the merge kernel read off[1], off[2], off[3])
+        hipLaunchKernelGGL(uq3_merge_kernel, dim3(256), dim3(256), 0, s, (const float4 *)vrec, merge3 - 1, (const u32 *)idx_alt, idx_merge);
         order.alt = idx_merge;
-        order.off = offsets;
+        order.off = merge3 - 1;
     }
     hipLaunchKernelGGL(uq3_rank_kernel, dim3((unsigned)ceil_div64(cap_v, 256)), dim3(256), 0, s, (const float4 *)vrec, cap_v, order,
                        uniq, table, (u64 *)tot, z_top);
     return tomo_status();
 }
 
-TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, const uint32_t *slice_tab,
+TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx, int64_t cap_v, int Nz, int Ny, const uint32_t *slice_tab,
                                 unsigned long long *tot, float *uniq, int32_t *table, void *workspace, int64_t workspace_bytes,
                                 void *stream)
 {
-    return tomo_mc3_sort_rank_top(vrec, keys, idx, cap_v, Nz, slice_tab, tot, uniq, table, workspace, workspace_bytes,
+    return tomo_mc3_sort_rank_top(vrec, keys, idx, cap_v, Nz, Ny, slice_tab, tot, uniq, table, workspace, workspace_bytes,
                                   __builtin_nanf(""), stream);
 }
 

@@ -13,6 +13,11 @@
 // vertex / voxel key = (row << TOMO_KEY_ROW_SHIFT) | (X << 2) | slot, row = Z * Ny + Y (mc.hip, mesh.hip)
 #define TOMO_KEY_ROW_SHIFT 22
 
+// Sort segments of the mc3 chain (mc.hip writes their offsets, mesh.hip sorts inside them): per slice Z the in-plane
+// vertices cut into bands of TOMO_SORT_BAND owner rows, then the between-plane vertices -- TOMO_SORT_NB(Ny) + 1 segments.
+#define TOMO_SORT_BAND 32
+#define TOMO_SORT_NB(Ny) (((Ny) + TOMO_SORT_BAND - 1) / TOMO_SORT_BAND)
+
 typedef unsigned long long u64;
 typedef unsigned int u32;
 

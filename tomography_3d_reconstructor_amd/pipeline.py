@@ -809,7 +809,7 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         m._vox_f3 = torch.empty(3 * cap, dtype=torch.float32, device=dev)
         m._vox_c3 = torch.empty(3 * cap, dtype=torch.float32, device=dev)
         m._blk3 = torch.empty(3 * nblk, dtype=torch.int32, device=dev)
-        m._slice_tab = torch.empty(L.tomo_mc3_slice_table_words(f.Nz), dtype=torch.int32, device=dev)
+        m._slice_tab = torch.empty(L.tomo_mc3_slice_table_words(f.Nz, f.Ny), dtype=torch.int32, device=dev)
         _lib.check(L.tomo_mc3_eval(_p(f.data), *geo, _p(m._vox_key), cap, _p(tot), int(z_offset), _p(m._vox_loc), _p(m._vox_til),
                                    _p(m._vox_flags), _p(m._vox_used), _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), st), "tomo_mc3_eval")
         _lib.check(L.tomo_mc3_scan(f.Nz, f.Ny, f.Nx, f.xorg, _p(seg_aoff), _p(m._vox_loc), cap, _p(m._blk3), _p(m._slice_tab), _p(tot),
@@ -821,13 +821,13 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         idx = torch.empty(cap_v, dtype=torch.int32, device=dev)
         m._uniq = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
         m.table = torch.empty(4 * cap, dtype=torch.int32, device=dev)
-        wsb = L.tomo_mc3_sort_workspace_bytes(cap_v)
+        wsb = L.tomo_mc3_sort_workspace_bytes(cap_v, L.tomo_mc3_sort_segments(f.Nz, f.Ny))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _lib.check(L.tomo_mc3_vertices(f.Nz, f.Ny, f.Nx, f.xorg, _p(m._vox_key), cap, _p(tot), _p(m._vox_loc), _p(m._vox_flags),
                                        _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), _p(m._slice_tab), int(z_offset), 1, _p(cum_t), ncum,
                                        _p(adj_t), nadj, mmy, mmx, _p(m._vrec), _p(keys), _p(idx), st), "tomo_mc3_vertices")
         m._cap_v = cap_v
-        _lib.check(L.tomo_mc3_sort_rank_top(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, _p(m._slice_tab), _p(tot), _p(m._uniq),
+        _lib.check(L.tomo_mc3_sort_rank_top(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, f.Ny, _p(m._slice_tab), _p(tot), _p(m._uniq),
                                             _p(m.table), _p(ws), wsb, z_top, st), "tomo_mc3_sort_rank_top")
 
     def complete(host, faces):
