@@ -267,7 +267,7 @@ int tomo_mc3_eval(const float *field, int Nz, int Ny, int Nx, int64_t pitch, int
                   uint32_t *vox_loc, int32_t *vox_til, uint8_t *vox_flags, uint16_t *vox_used, float *vox_f3, float *vox_c3,
                   uint32_t *blk3, void *stream);
 int64_t tomo_mc3_slice_table_words(int Nz, int Ny);
-int64_t tomo_mc3_sort_segments(int Nz, int Ny);      /* sort segments: per slice ceil(Ny / 32) bands of owner rows of the plane + the between-plane bucket */
+int64_t tomo_mc3_sort_segments(int Nz, int Ny);      /* sort segments: per slice its plane (cut into bands of 512 owner rows when Ny > 1280) + the between-plane bucket */
 int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg_aoff, const uint32_t *vox_loc, int64_t cap,
                   uint32_t *blk3, uint32_t *slice_tab, unsigned long long *tot, int64_t cap_v, int64_t cap_f, void *stream);
 int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned long long *vox_key, int64_t cap,

@@ -1029,11 +1029,11 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_eval_kernel(const float *__restri
 
 // ---- scan: block sums -> exclusive prefixes, totals and the per-slice tables; mc3_bands_kernel then writes the offsets of the
 // sort's segments.  slice_tab: sliceA[Nz + 1] | sliceB[Nz + 1] | offsets[(NB + 1) Nz + 1] | merge3[3]  (uint32), NB =
-// TOMO_SORT_NB(Ny): per slice NB bands of TOMO_SORT_BAND owner rows of in-plane vertices, then the between-plane vertices.
+// TOMO_SORT_NB(Ny): per slice NB bands of tomo_sort_band(Ny) owner rows of in-plane vertices, then the between-plane vertices.
 // In a plane the vertices arrive grouped by owner row and a vertex of owner row Y has its key y' in [Y, Y + 1] * mm_y, so the
-// sort is local to a row -- a fortiori to a band of rows: ~100 entries per segment instead of 3 400 (1024^2 slices) or 6 700
-// (2048^2: beyond what the segmented sort keeps in LDS -- 922 us for 3.7 M vertices on a middle rank of BASELINE configs[4],
-// profiles/r03_slab_selfloop.md).  The between-plane keys z' are in no order: those buckets stay whole.
+// sort is local to a row -- a fortiori to a band of rows: planes of more than 1280 rows are cut into bands of 512 (2048^2
+// slices hold ~6 700 vertices per plane, beyond what the segmented sort keeps in LDS -- 922 us for 3.7 M vertices on a
+// middle rank of BASELINE configs[4]; tomo_common.h).  The between-plane keys z' are in no order: those buckets stay whole.
 // merge3 = {start of slab 0's between-plane bucket, start of slab 1's plane, its end}: the two runs uq3_merge_kernel merges.
 __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
                                                         const u32 *__restrict__ vox_loc, int64_t cap, u32 *__restrict__ blk3,
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
     }
 }
 
-// one thread per sort segment (Z, b): b < NB the band of owner rows [b, b + 1) * TOMO_SORT_BAND of plane Z, b == NB the
+// one thread per sort segment (Z, b): b < NB the band of owner rows [b, b + 1) * tomo_sort_band(Ny) of plane Z, b == NB the
 // between-plane bucket; on overflow (tot[3]) every segment is empty: the sort touches nothing
 __global__ __launch_bounds__(256) void mc3_bands_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
                                                         const u32 *__restrict__ vox_loc, const u32 *__restrict__ blk3,
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256) void mc3_bands_kernel(const McGrid g, const u3
             o = sliceA[Z + 1] + sliceB[Z];
         } else {
             // in-plane vertices before the first voxel of row (Z, b * BAND): the list position of that voxel, then its prefix
-            const u64 s = seg_aoff[((int64_t)Z * g.Ny + (int64_t)b * TOMO_SORT_BAND) * g.segs_per_row];
+            const u64 s = seg_aoff[((int64_t)Z * g.Ny + (int64_t)b * tomo_sort_band(g.Ny)) * g.segs_per_row];
             const u32 a = s < na ? blk3[s >> 8] + MC3_LOC_A(vox_loc[s]) : sliceA[Nz];
             o = a + sliceB[Z];
         }

@@ -273,7 +273,10 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // (128 threads x 17 items) sorts at most 2 176 of them in one go and sends longer segments through several global-memory
 // passes of one small block: 512 x 8 keeps every segment up to 4 096 in registers / LDS (measured, unique stage at 1024^3:
 // default 0.43 ms, 256x16 0.32, 512x8 0.315, 1024x4 0.36, 512x6 0.35, 512x10 0.36, 256x24 0.39).
-typedef rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<512, 8>, rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>, true>
+// The partitioning threshold (4th WarpSortConfig parameter: the number of SEGMENTS from which rocPRIM first partitions them by
+// size) is set out of reach: that path copies its segment counts to the host and waits for them (device_segmented_radix_sort.hpp,
+// memcpy_and_sync) -- one hidden host round trip per pass of a chain that is built to have none until its single download.
+typedef rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<512, 8>, rocprim::WarpSortConfig<32, 4, 256, 0x7fffffff, 32, 4, 256>, true>
     UqSegCfg;
 
 

@@ -4,9 +4,11 @@
 RCCL refuses two ranks on one device, so this is a rehearsal, not a measurement of a multi-GPU run: ONE process plays a
 middle rank (rank 1 of a pretend world of 3) and every message it would send to a neighbour goes to ITSELF through a
 real world-size-1 `nccl` process group -- the same batched isend / irecv of uint8 views and the same all-gather the job
-uses, enqueued on the same streams.  What arrives "from below" is what was sent "up" (and vice versa), so the halo
-content is not that of a real stack (the mesh has a seam and is not checked); sizes, kernels, launches, host round trips
-and the RCCL calls are those of a middle rank.  What is missing is the time on the xGMI link (3 MB per pass).
+uses, enqueued on the same streams.  What arrives "from below" is what was sent "up" (and vice versa); the edge slices of
+the pass's front are then overwritten with what the real neighbours would have sent (generated here: the stack is synthetic), so
+the kernels see a seam-free stack -- with the rank's own slices as halo the seam put flat caps of 10^5 vertices into single sort
+buckets and the segmented sort took 0.9 ms instead of 0.1 (round 3).  Sizes, kernels, launches, host round trips and the RCCL
+calls are those of a middle rank; the mesh is not checked.  What is missing is the time on the xGMI link (3 MB per pass).
 usage: slab_selfloop_bench.py [slices_per_rank] [ny] [nx] [steps] [world=3] [rank=world//2]
 (BASELINE configs[4] per rank: 512 2048 2048 10 8 3 -- slab 3 of the 8 slabs of the 2048 x 2048 x 4096 stack)"""
 import datetime
@@ -80,6 +82,18 @@ class SelfLoopRccl:
             def _peer(self, r):
                 return 0
 
+            def exchange(self, to_prev, to_next, dtype, recv_shape_prev=None, recv_shape_next=None):
+                got = rccl.RcclComm.exchange(self, to_prev, to_next, dtype, recv_shape_prev, recv_shape_next)
+                # the edge slices of the pass's front: what arrived is this rank's own (sent to itself) -- a seam, with flat caps
+                # of 10^5 vertices in the halo that a real neighbour would not produce.  Overwritten (two small device copies)
+                # with what the real neighbours WOULD have sent, so that the kernels behind see a seam-free stack.
+                truth = getattr(self, "truth", None)
+                if truth is not None and dtype == torch.int64 and got[0] is not None and got[1] is not None \
+                        and got[0].shape == truth[0].shape and got[1].shape == truth[1].shape:
+                    got[0].copy_(truth[0])
+                    got[1].copy_(truth[1])
+                return got
+
             def all_gather(self, t):
                 return [rccl.RcclComm.all_gather(self, t)[0]] * self.world
 
@@ -116,6 +130,11 @@ def main():
     job = slab.SlabJob(gz, ny, nx, comm)
     mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
     depths = np.full(gz, 1.0)
+    if direct and 0 < rank < world - 1:
+        H = job.halo                       # original edge slices the neighbours send: H + 1 from below, H + 2 from above (slab.py)
+        lo = pipeline.pack(pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0 - (H + 1), job.z0).view(torch.uint8)).bits
+        hi = pipeline.pack(pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z1, job.z1 + H + 2).view(torch.uint8)).bits
+        comm.truth = (lo, hi)
     res = None
     for _ in range(4):
         res = job.run(mask, depths, 1.0, 1.0)
@@ -141,6 +160,24 @@ def main():
     slab_ms = (time.perf_counter() - t0) / steps * 1e3
     st = dict(comm.stats)
     nv, nf = int(res[0].shape[0]), int(res[1].shape[0])
+    if os.environ.get("DUMP_SEGS"):                         # sizes of the sort's segments of one more pass of this rank
+        from tomography_3d_reconstructor_amd import _lib
+        keep = {}
+        orig = job._numbering_deferred_finish
+        def spy(t):
+            keep["m"] = t["m"]
+            return orig(t)
+        job._numbering_deferred_finish = spy
+        job.run(mask, depths, 1.0, 1.0)
+        m = keep["m"]; f = m._f
+        nseg = int(_lib.lib().tomo_mc3_sort_segments(f.Nz, f.Ny))
+        tab = m._slice_tab.cpu().numpy().view(np.uint32)
+        off = tab[2 * (f.Nz + 1): 2 * (f.Nz + 1) + nseg + 1].astype(np.int64)
+        sz = np.diff(off)
+        per = sz.reshape(f.Nz, nseg // f.Nz)
+        print("segments: Nz %d Ny %d, %d segments, sizes max %d mean %.0f, > 4096: %d; monotone: %s; cap_v %d nv %d; per-slice max per column %s; slice 0 %s, slice -1 %s"
+              % (f.Nz, f.Ny, nseg, sz.max(), sz.mean(), (sz > 4096).sum(), bool((sz >= 0).all()), m._cap_v, m.nv, per.max(axis=0).tolist(),
+                 per[0].tolist(), per[-1].tolist()), flush=True)
     del res
     # host time of submit() alone: enqueue 4 passes back to back without reading any, then collect them
     torch.cuda.synchronize()
