@@ -204,10 +204,20 @@ def cpu_baseline(n):
     res = se.extract_manifold_surface(sm, vp.calculate_slice_depths(float(n)), 1.0, 1.0)
     dt = time.perf_counter() - t0
     assert res is not None
-    return {"value": round(n ** 3 / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": "%dx%dx%d ellipsoid, whole path (close ends + smooth + field + MC + unique), %.1f s; "
-                      "host has %d cores" % (n, n, n, dt, os.cpu_count() or 0),
-            "n_vertices": int(len(res[0])), "n_faces": int(len(res[1]))}
+    out = {"value": round(n ** 3 / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+           "sample": "%dx%dx%d ellipsoid, whole path (close ends + smooth + field + MC + unique), %.1f s; "
+                     "host has %d cores" % (n, n, n, dt, os.cpu_count() or 0),
+           "n_vertices": int(len(res[0])), "n_faces": int(len(res[1]))}
+    try:
+        # the REFERENCE itself (NumPy / SciPy 1.7.1 / scikit-image 0.18.3, one thread), timed once in the build container when
+        # the golden hashes were made -- not on this box, quoted for scale: the C port above is ~10x faster than it
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ellipsoid_hashes.json")))["1024x1024x1024"]
+        out["reference_itself"] = {"value": round(1024 ** 3 / ref["reference_seconds"] / 1e6, 2), "unit": "Mvoxels/s",
+                                   "where": "build container (8-core Xeon, 1 thread used), 1024^3, %.0f s; tests/golden/ellipsoid_hashes.json"
+                                            % ref["reference_seconds"]}
+    except Exception:       # noqa: BLE001
+        pass
+    return out
 
 
 def host_to_host(mask_dev, nz):
