@@ -106,7 +106,38 @@ def launch_plan(args, env, argv):
     return ("run", world)
 
 
-def supervise(cmd, env, run=subprocess.call):
+def _run_worker(cmd, env):
+    """Start the worker as a child that cannot outlive this supervisor: it dies with it (PR_SET_PDEATHSIG) and a SIGTERM /
+    SIGINT sent to the supervisor -- torch.distributed.run tearing the job down -- is handed on.  -> the worker's exit code."""
+    import ctypes
+    import signal
+
+    def die_with_parent():
+        try:
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)      # PR_SET_PDEATHSIG
+        except Exception:                                                         # noqa: BLE001
+            pass
+    child = subprocess.Popen(cmd, env=env, preexec_fn=die_with_parent)
+    old = {}
+
+    def forward(signum, _frame):
+        try:
+            child.send_signal(signum)
+        except Exception:                                                         # noqa: BLE001
+            pass
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sig] = signal.signal(sig, forward)
+        except Exception:                                                         # noqa: BLE001
+            pass
+    try:
+        return child.wait()
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
+
+
+def supervise(cmd, env, run=_run_worker):
     """A rank launched by torch.distributed.run does not touch the GPU itself: it starts the real worker as a CHILD process
     and relays its exit code.  RCCL's C API (rccl.py, the default transport of the Z-slab job) has no timeout of its own; a
     worker whose watchdog finds no progress for two minutes -- communicator creation, preflight, a pass -- leaves with code 4,
@@ -294,6 +325,9 @@ def run(args, world):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1 or args.rehearse_dist
+    if (os.environ.get("TOMO_BENCH_FAKE_HANG") and os.environ.get("TOMO_BENCH_WORKER")
+            and os.environ.get("TOMO_RCCL_DIRECT", "1") not in ("", "0")):
+        os._exit(4)         # test hook: a worker on the direct transport "hangs" (what the watchdog's exit looks like to the supervisor)
     if args.rehearse_dist and world == 1:
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(args.master_port or _free_port())), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
@@ -602,7 +636,8 @@ def main(argv=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "4")
         return subprocess.call(plan[1], env=env)
-    if plan[1] > 1 and args.backend == "nccl" and not os.environ.get("TOMO_BENCH_WORKER"):
+    supervised = (plan[1] > 1 and args.backend == "nccl") or os.environ.get("TOMO_BENCH_SUPERVISE") == "1"    # (the latter: test hook)
+    if supervised and not os.environ.get("TOMO_BENCH_WORKER"):
         # a rank of a multi-GPU run: supervise a worker child (this process never initialises the GPU, so this is a child
         # process, not an exec of a GPU process)
         return supervise([sys.executable, os.path.abspath(__file__)] + list(argv), os.environ)

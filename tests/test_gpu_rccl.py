@@ -55,6 +55,34 @@ def test_bench_multi_rank_plumbing_with_one_rank():
     assert (d2["config"]["n_vertices"], d2["config"]["n_faces"]) == (d["config"]["n_vertices"], d["config"]["n_faces"])
 
 
+def test_rank_supervisor_relays_the_worker_and_retries_after_a_hang():
+    """bench.py under a multi-rank launch is a supervisor per rank around a worker child (bench.supervise).  Forced here for the
+    one-rank rehearsal (TOMO_BENCH_SUPERVISE=1): the worker's ONE JSON line and exit code come through; and a worker that leaves
+    with the watchdog's code 4 (TOMO_BENCH_FAKE_HANG: only while it is on the direct RCCL transport) is replaced once by one on
+    torch.distributed's collectives, on the next rendezvous port."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-dist", "--size", "160", "128", "192", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    base = {k: v for k, v in os.environ.items() if k not in ("TOMO_BENCH_WORKER", "TOMO_RCCL_DIRECT")}
+    env = dict(base, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", TOMO_BENCH_SUPERVISE="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["comm"]["backend"] == "rccl-direct", lines
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, TOMO_BENCH_FAKE_HANG="1"))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "one retry over torch.distributed's collectives" in p.stderr
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["comm"]["backend"] == "nccl", lines
+
+
 def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
     """bench.py --gpus 2 --backend gloo: two rank PROCESSES sharing this GPU, halos staged through the host -- the whole
     multi-rank code path of the bench (self-launch, process group, TorchDistComm, preflight, one-exchange front, deferred
@@ -67,7 +95,10 @@ def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
     nzr, ny, nx = 160, 96, 128
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", str(nzr), str(ny), str(nx),
            "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TOMO_BENCH_WORKER")}
+    # TOMO_BENCH_SUPERVISE=1: every rank process is a supervisor around a worker child, as under an `nccl` launch -- the real
+    # process tree (self-launch -> torch.distributed.run -> rank supervisors -> workers), environment and output relayed
+    env["TOMO_BENCH_SUPERVISE"] = "1"
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
