@@ -1416,13 +1416,16 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
     // ---- staged path: load instruction q covers rows 16 q .. 16 q + 15 (4 lanes a row), store instruction q rows
     //      32 q .. 32 q + 31 (2 lanes a row)
     unsigned char *lb = s_stage + (STAGED ? wv * WAVE_LDS : 0), *sb = lb + (STAGED ? 64 * LB_PITCH : 0);
-    uint4 G[4];
+#ifndef FW_AHEAD
+#define FW_AHEAD 1      // slices of prefetch in flight.  2 (a second set of four 16-byte registers) measured SLOWER: 0.184 against
+#endif                  // 0.177 ms for the eight passes at 1024^3, 1.61 against 1.45 ms at 2048^3 (round 3)
+    uint4 G2[FW_AHEAD][4];
     const int lrow = lane >> 2, lpart = lane & 3, lwp = w0 - 2 + 2 * lpart;       // first word of this lane's 16 bytes
     const bool lpv = lwp >= 0 && lwp < wx;
     const int srow = lane >> 1, spart = lane & 1, swp = w0 + 2 * spart;
     const bool spv = swp < wx;
 
-#define FW_ISSUE(tt)                                                                             \
+#define FW_ISSUE(G, tt)                                                                          \
     {                                                                                            \
         const int tc = (tt) < 0 ? 0 : ((tt) >= nz ? nz - 1 : (tt));                              \
         const u64 *sl = in + (int64_t)tc * sw;                                                   \
@@ -1431,7 +1434,7 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
             if (lpv && yy >= 0 && yy < ny) G[q] = *(const uint4 *)(sl + (int64_t)yy * wx + lwp); \
         }                                                                                        \
     }
-#define FW_LAND(dst)                                                                             \
+#define FW_LAND(G, dst)                                                                          \
     {                                                                                            \
         _Pragma("unroll") for (int q = 0; q < 4; q++)                                            \
             *(uint4 *)(lb + (16 * q + lrow) * LB_PITCH + 16 * lpart) = G[q];                     \
@@ -1455,8 +1458,13 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
     }
     if (STAGED) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) G[q] = make_uint4(0, 0, 0, 0);
-        FW_ISSUE(za - H);
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int a = 0; a < FW_AHEAD; a++) G2[a][q] = make_uint4(0, 0, 0, 0);
+        // the loop is unrolled by two slices (p = 0, 1): with two slices of prefetch slice t lands from set p and slice t + 2 is
+        // issued into it right afterwards; with one, everything goes through set 0
+        FW_ISSUE(G2[0], za - H);
+        if (FW_AHEAD == 2) FW_ISSUE(G2[1], za - H + 1);
     } else {
         FW_LOAD32(X[0][0], za - H);
     }
@@ -1468,7 +1476,7 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
                 if (STAGED) {
                     // top of the iteration: land the prefetched slice, store the slice finished in the previous iteration,
                     // issue the next loads -- all before the first level, so the loads have the whole iteration to arrive
-                    FW_LAND(X[p][0]);
+                    FW_LAND(G2[FW_AHEAD == 2 ? p : 0], X[p][0]);
                     const int so = t - 1 - H;
                     const bool sv = so >= za && so < zb;
                     if (sv) {
@@ -1486,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void morph_wave32_kernel(const u64 *__restr
                             if (spv && r >= H && r < 64 - H && yy >= 0 && yy < ny) *(uint4 *)(sl + (int64_t)yy * wx + swp) = v;
                         }
                     }
-                    FW_ISSUE(t + 1);
+                    FW_ISSUE(G2[FW_AHEAD == 2 ? p : 0], t + FW_AHEAD);
                 }
 #pragma unroll
                 for (int j = 0; j < H; j++) {
