@@ -33,7 +33,7 @@ def run(seed=0, cases=20):
 
     for it in range(cases):
         world = int(rng.integers(2, 5))
-        thick = int(rng.integers(11, 40)) if it % 2 else int(rng.integers(4 * slab.PC_EDGE, 4 * slab.PC_EDGE + 24))
+        thick = int(rng.integers(11, 40)) if it % 2 else int(rng.integers(slab.MERGED_MIN, slab.MERGED_MIN + 24))
         nz = world * thick + int(rng.integers(0, world))
         ny = int(rng.integers(8, 48))
         nx = 16 * int(rng.integers(1, 6)) if it % 3 else int(rng.integers(8, 90))          # nx % 16 != 0: the unfused front

@@ -187,12 +187,12 @@ def test_slab_kernels_take_counts_from_device_memory(dev):
 
 @pytest.mark.parametrize("world,nz", [(2, 300), (3, 391)])
 def test_merged_edge_exchange_matches_single_gpu(dev, world, nz):
-    """Slabs of at least 4 * PC_EDGE slices take the one-exchange front: ORIGINAL edge slices travel while the middle of the
+    """Slabs of at least MERGED_MIN slices take the one-exchange front: ORIGINAL edge slices travel while the middle of the
     slab is packed + closed, every rank closes its neighbours' halo slices itself.  Noisy stack with holes in both end
     slices and structure right at the slab boundaries; two passes (exact, deferred), meshes and closed / smoothed volumes
     byte-identical to the single-GPU path."""
     ny, nx = 40, 80
-    assert nz // world >= 4 * slab.PC_EDGE
+    assert nz // world >= slab.MERGED_MIN
     rng = np.random.default_rng(nz)
     v = blob(nz, ny, nx, 1.0, nz)
     v ^= rng.random(v.shape) < 0.01

@@ -35,7 +35,11 @@ import torch
 from . import pipeline
 
 HALO_BITS = 10   # 8 morphology passes + 2 slices for the 5-tap Gaussian along z
-PC_EDGE = 32     # slices at either end of a slab that wait for the neighbours' slices (the rest is packed + closed first)
+PC_EDGE = 4      # slices at either end of a slab that wait for the neighbours' slices (the rest is packed + closed first).  Only the
+#                  first and the last slice of a slab read a neighbour's slice (the stencil has radius 1 on ORIGINAL slices); 4 = one
+#                  group of the streaming kernel's march.  (Rounds 2-3a: 32 -- 64 slices per rank through the short-run kernel at
+#                  2/3 of the middle's rate: 78 us of a BASELINE configs[4] rank's pass.)
+MERGED_MIN = 128 # slices per rank from which the one-exchange front is used (thinner slabs: the two-exchange front)
 SPLIT_PACK = os.environ.get("TOMO_SLAB_SPLIT", "1") not in ("", "0")              # middle of the slab before the neighbour chain (A/B switch)
 DEFERRED_NUMBERING = os.environ.get("TOMO_SLAB_DEFERRED", "1") not in ("", "0")   # the pass with ONE download (A/B switch)
 
@@ -309,7 +313,7 @@ class HipEngine:
             # transfer -- and every rank closes its neighbours' halo slices itself (the stencil needs one slice more on
             # either side: the reason for the + 1) instead of receiving them closed in a second exchange.
             H, Hu = halo
-            assert room >= Hu >= H and E >= Hu + 1 and nzl >= 4 * E
+            assert room >= Hu >= H and nzl >= MERGED_MIN and nzl >= 4 * E and nzl > 2 * (Hu + 1)
             zc = (E + (nzl - 2 * E) * 3 // 4) // 4 * 4        # 3/4 before the RCCL call (its host side takes ~0.15 ms), 1/4 after
             close_range(E, zc)
             edge_lo = torch.empty((Hu + 1, ny, wx), dtype=torch.int64, device=mask.device)
@@ -612,7 +616,7 @@ class SlabJob:
         if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
             # one exchange of ORIGINAL edge slices instead of two (stencil neighbours, then closed halos): a joint decision,
             # so it goes by the thinnest slab of the job, not by this rank's
-            merged = (SPLIT_PACK and self.gz // self.world >= 4 * PC_EDGE and PC_EDGE >= Hu + 1 and hasattr(c, "exchange_async")
+            merged = (SPLIT_PACK and self.gz // self.world >= MERGED_MIN and hasattr(c, "exchange_async")
                       and self.nx % 16 == 0 and pipeline.PACK_CLOSE_FUSED)
             fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last, (H, Hu), merged)
         if fused is not None:
