@@ -37,3 +37,22 @@ def test_host_touch_and_reservations():
     x[:] = True
     y[:] = 7
     assert x.all() and (y == 7).all()
+
+
+def test_protected_results_cannot_be_written_through_their_base():
+    """_devcache.put(protect=True) write-protects the array AND every ndarray it is a view of: the volume-sized results are typed
+    views of a byte buffer (_hostbuf.take), and a cached device copy is trusted for as long as the array is read-only."""
+    from tomography_3d_reconstructor_amd import _devcache
+    if _devcache.WRITEABLE_RESULTS:
+        pytest.skip("TOMO_WRITEABLE_RESULTS: results stay writeable and are verified by checksum instead")
+    a = _hostbuf.take((4, 5, 6), np.bool_)
+    a[:] = True
+    assert isinstance(a.base, np.ndarray) and a.base.flags.writeable
+    _devcache.put(a, object())
+    assert not a.flags.writeable and not a.base.flags.writeable
+    with pytest.raises(ValueError):
+        a.base[0] = 0
+    assert _devcache.get(a) is not None                       # read-only all the way down: the remembered copy is exact
+    a.base.setflags(write=True)                               # the owner of the bytes CAN be re-enabled (NumPy allows it) ...
+    a.base[0] = 0
+    assert _devcache.get(a) is None                           # ... and the remembered copy is then no longer trusted

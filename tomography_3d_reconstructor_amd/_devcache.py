@@ -58,6 +58,10 @@ def put(arr, vol, protect=True):
     digest = None
     if protect and not WRITEABLE_RESULTS:
         arr.flags.writeable = False
+        b = arr.base                 # ... and what it is a view of (the arrays of _hostbuf are typed views of a byte buffer):
+        while isinstance(b, np.ndarray):      # no door may stay open behind a write-protected result
+            b.flags.writeable = False
+            b = b.base
     else:
         digest = checksum(arr)
     _cache[key] = (ref, _layout(arr), digest, vol)
@@ -74,8 +78,9 @@ def get(arr):
     if ref() is not arr or layout != _layout(arr):
         _cache.pop(id(arr), None)
         return None
-    if arr.flags.writeable:
-        # the caller could have written into it: only a full comparison makes the cached copy usable
+    if arr.flags.writeable or _base_writeable(arr):
+        # the caller could have written into it -- directly, or through an array it is a view of (put() write-protects those
+        # too; one that is writeable again was re-enabled on purpose): only a full comparison makes the cached copy usable
         if digest is None:
             STATS["miss_unverifiable"] += 1
             _cache.pop(id(arr), None)
@@ -86,15 +91,7 @@ def get(arr):
             return None
         STATS["hit_verified"] += 1
     else:
-        if digest is not None and _base_writeable(arr):
-            # read-only view of memory somebody else can still write (not one of this package's own hand-outs)
-            if checksum(arr) != digest:
-                STATS["miss_edited"] += 1
-                _cache.pop(id(arr), None)
-                return None
-            STATS["hit_verified"] += 1
-        else:
-            STATS["hit_readonly"] += 1
+        STATS["hit_readonly"] += 1
     _cache.move_to_end(id(arr))
     return vol
 
