@@ -178,41 +178,6 @@ def test_create_voxel_data_input_forms(dev):
         VoxelProcessor().create_voxel_data([], True)
 
 
-@pytest.mark.parametrize("shape,piece", [((40, 48, 64), 20000), ((37, 33, 80), 9000), ((64, 64, 128), 70000), ((9, 16, 16), 600)])
-def test_pipelined_create_voxel_data_matches_the_plain_sequence(dev, shape, piece, monkeypatch):
-    """create_voxel_data(close_ends=True) on a list of separate masks runs upload, close-ends and download piece by piece at the
-    same time (voxel_processor._create_closed_pipelined) once the stack is large enough; here the piece size is shrunk so that
-    small stacks take that path: result, printed count and the remembered device copy must equal the oracle's / the plain
-    sequence's -- end slices with holes (they are filled before anything around them is closed), piece boundaries anywhere."""
-    from tomography_3d_reconstructor_amd import voxel_processor as VP
-    nz, ny, nx = shape
-    rng = np.random.default_rng(nz + nx)
-    v = rng.random(shape) < 0.45
-    v[0] = False
-    v[0, 3:ny - 3, 4:nx - 4] = True
-    v[0, 6:9, 8:14] = False                              # a hole in the first slice
-    v[-1, 2:ny - 2, 2:nx - 2] = True
-    v[-1, 5:7, 5:9] = False
-    masks = [m.copy() for m in v]
-    exp = O.VoxelProcessor().create_voxel_data([m.copy() for m in v], True, 0, nz, 0)
-    monkeypatch.setattr(VP, "PIPE_PIECE_BYTES", piece)
-    calls = []
-    orig = VP._create_closed_pipelined
-    monkeypatch.setattr(VP, "_create_closed_pipelined", lambda m: calls.append(1) or orig(m))
-    with contextlib.redirect_stdout(io.StringIO()) as said:
-        got = VoxelProcessor().create_voxel_data(masks, True, 0, nz, 0)
-    assert calls and VP._create_closed_pipelined(masks) is not None, "the pipelined path was not taken"
-    assert got.dtype == np.bool_ and np.array_equal(got, exp)
-    assert "active: %s" % format(int(exp.sum()), ",") in said.getvalue()
-    assert np.array_equal(pipeline.unpack(_devcache.get(got)).cpu().numpy(), exp)
-    monkeypatch.setattr(VP, "PIPELINED_CREATE", False)
-    with contextlib.redirect_stdout(io.StringIO()):
-        plain = VoxelProcessor().create_voxel_data(masks, True, 0, nz, 0)
-    assert np.array_equal(plain, exp)
-    sm = VoxelProcessor().smooth_voxel_data(got, 3, True)          # the remembered copy feeds the next call
-    assert np.array_equal(sm, O.smooth(exp, 3, True))
-
-
 def test_repeated_calls_reuse_the_device_result(dev):
     """the orchestrator repeats smooth_voxel_data / extract_manifold_surface with the same arguments
     (tomography_3d_reconstruction.py:201-243).  The device result is remembered; every call still returns FRESH, equal

@@ -6,7 +6,6 @@ device copy of every returned volume is cached (see _devcache: returned volumes 
 writeable array is verified byte for byte before its cached copy is used) so the orchestrator's next call does
 not upload it again.  There is no CPU fallback: without a GPU / the built library these methods raise.
 """
-import os
 import sys
 import threading
 
@@ -83,10 +82,10 @@ def _staging(shape):
     return a
 
 
-def _stage_masks(mask_images, on_piece=None, piece_bytes=128 << 20):
-    """np.stack(mask_images) (voxel_processor.py:46) into a host staging array and, piece by piece behind it, onto the device:
-    -> (nz, ny, nx) uint8 0/1 on the device.  on_piece(dev_u8, lo, hi), if given, is called on this thread right after the
-    slices [lo, hi) have been uploaded (the pipelined create_voxel_data closes and downloads what it can meanwhile)."""
+def _stage_masks(mask_images):
+    """np.stack(mask_images) (voxel_processor.py:46) straight into a page-locked staging tensor, copied by a few host
+    threads (NumPy releases the GIL while copying) and uploaded chunk by chunk behind them: (nz, ny, nx) uint8 0/1 on
+    the device."""
     from concurrent.futures import ThreadPoolExecutor
     import os
     first = np.asarray(mask_images[0])
@@ -101,7 +100,7 @@ def _stage_masks(mask_images, on_piece=None, piece_bytes=128 << 20):
     # uploads in pieces of >= 128 MiB (below that ROCm stages a pageable source through its own buffers at a fraction of the
     # bus rate; above it the source is page-locked on the fly: 1 GiB in 8 pieces 19 ms, in 32 pieces 90-120 ms)
     per_slice = max(first.size, 1)
-    up = max(1, min(nz, -(-int(piece_bytes) // per_slice)))                                      # slices per upload piece
+    up = max(1, min(nz, -(-(128 << 20) // per_slice)))                                           # slices per upload piece
     dev = torch.empty((nz,) + first.shape, dtype=torch.bool, device=_device())
     # Fast path (what an image loader produces: separate C-contiguous bool / uint8-of-0/1... arrays of one shape): the
     # stacking is a native multi-threaded gather (tomo_host_gather) -- piece k + 1 is gathered on a helper thread while
@@ -126,8 +125,6 @@ def _stage_masks(mask_images, on_piece=None, piece_bytes=128 << 20):
             for (lo, hi), fut in zip(spans, futs):
                 fut.result()
                 dev[lo:hi].copy_(torch.from_numpy(stage[lo:hi]))
-                if on_piece is not None:
-                    on_piece(dev.view(torch.uint8), lo, hi)
         return dev.view(torch.uint8)
     workers = max(1, min(8, os.cpu_count() or 1, nz))
     fine = max(1, -(-up // workers))                                                           # slices per worker task
@@ -147,77 +144,7 @@ def _stage_masks(mask_images, on_piece=None, piece_bytes=128 << 20):
             for fut in futs:
                 fut.result()
             dev[lo:hi].copy_(torch.from_numpy(stage[lo:hi]))
-            if on_piece is not None:
-                on_piece(dev.view(torch.uint8), lo, hi)
     return dev.view(torch.uint8)
-
-
-_SIDE = {}           # device -> the stream the pipelined create_voxel_data downloads on
-PIPELINED_CREATE = os.environ.get("TOMO_CREATE_PIPELINED", "1") not in ("", "0")
-PIPE_PIECE_BYTES = 160 << 20   # > 128 MiB after the one slice a piece waits for: ROCm's fast path for pageable memory (tests shrink it)
-
-
-def _create_closed_pipelined(mask_images):
-    """create_voxel_data(close_ends=True) for a list of separate masks with the upload, the close-ends pass and the download
-    of the result running AT THE SAME TIME, piece by piece: the bus is full duplex, and the three steps one after the other
-    (19 + 1 + 21 ms at 1024^3) are most of a call that hands a gibibyte in and a gibibyte back.  The closed slice z needs the
-    ORIGINAL slices z - 1 and z + 1, so once piece k is up, everything below its last slice is closed
-    (tomo_pack_close_range), unpacked and handed to a helper thread that copies it into the result array on a second stream
-    while this thread uploads piece k + 1.  The two end slices are packed and filled as soon as they are on the device.
-    -> (BitVolume, host bool ndarray) or None when the layout needs the plain sequence (tomo_pack_close_range wants nx % 16 == 0,
-    16-byte aligned slices; stacks of fewer than four pieces gain nothing)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from . import _lib
-    first = np.asarray(mask_images[0])
-    nz = len(mask_images)
-    if first.ndim != 2 or not PIPELINED_CREATE or not pipeline.PACK_CLOSE_FUSED:
-        return None
-    ny, nx = first.shape
-    piece_bytes = PIPE_PIECE_BYTES
-    if nx % 16 != 0 or (ny * nx) % 16 != 0 or nz * ny * nx < 4 * piece_bytes or nz < 8:
-        return None
-    L = _lib.lib()
-    dev = _device()
-    wx = L.tomo_words_per_row(nx)
-    bits = torch.empty((nz, ny, wx), dtype=torch.int64, device=dev)
-    scratch = torch.empty(ny * wx + 8, dtype=torch.int64, device=dev)
-    out = _hostbuf.take((nz, ny, nx), np.bool_)
-    out_t = torch.from_numpy(out)
-    side = _SIDE.get(str(dev))
-    if side is None:
-        side = _SIDE[str(dev)] = torch.cuda.Stream(device=dev)
-    st = torch.cuda.current_stream()
-    state = {"closed": 0}
-    jobs = []
-
-    def download(piece, a, b, ev):
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            out_t[a:b].copy_(piece.view(torch.bool))          # returns when the bytes are in `out`
-
-    with ThreadPoolExecutor(1) as pool:
-        def on_piece(mask_u8, lo, hi):
-            if mask_u8.data_ptr() % 16 != 0:
-                raise _lib.TomoError("device mask is not 16-byte aligned")
-            s = st.cuda_stream
-            for z in ([0] if lo == 0 else []) + ([nz - 1] if hi == nz else []):
-                _lib.check(L.tomo_pack_bits(mask_u8[z].data_ptr(), bits[z].data_ptr(), 1, ny, nx, s), "tomo_pack_bits")
-                _lib.check(L.tomo_fill_holes_slice(bits.data_ptr(), nz, ny, nx, z, scratch.data_ptr(), s), "tomo_fill_holes_slice")
-            a, b = state["closed"], (nz if hi == nz else hi - 1)
-            if b <= a:
-                return
-            _lib.check(L.tomo_pack_close_range(mask_u8.data_ptr(), bits.data_ptr(), nz, ny, nx, a, b, None, None, 1, 1, s),
-                       "tomo_pack_close_range")
-            piece = pipeline.unpack(pipeline.BitVolume(bits[a:b], (b - a, ny, nx)))
-            piece.record_stream(side)
-            ev = torch.cuda.Event()
-            ev.record(st)
-            jobs.append(pool.submit(download, piece, a, b, ev))
-            state["closed"] = b
-        _stage_masks(mask_images, on_piece, piece_bytes)
-        for j in jobs:
-            j.result()
-    return pipeline.BitVolume(bits, (nz, ny, nx)), out
 
 
 def _common_base(mask_images):
@@ -234,10 +161,6 @@ def _common_base(mask_images):
                 m.strides == base.strides[1:] and m.__array_interface__["data"][0] == ptr0 + i * step):
             return None
     return base
-
-
-def nz_ok(mask_images):
-    return len(mask_images) >= 3
 
 
 class VoxelProcessor:
@@ -268,21 +191,15 @@ class VoxelProcessor:
             # copy is dropped for good (a later lookup must not find it either) and the stack is uploaded again
             _devcache.invalidate(base)
             cached = None
-        piped = None
         if close_ends:
             if cached is not None:                           # uploaded (and thresholded) by ImageLoader already: closed into a COPY
                 vol = pipeline.close_ends(cached)
             elif base is not None:
                 vol = pipeline.close_ends(upload_volume(base), inplace=True)           # a fresh upload, never a cached volume: ours to overwrite
             else:
-                piped = _create_closed_pipelined(mask_images) if nz_ok(mask_images) else None
-                vol = piped[0] if piped is not None else pipeline.pack_closed(_stage_masks(mask_images))
+                vol = pipeline.pack_closed(_stage_masks(mask_images))
             active = int(pipeline.popcount_async(vol).item())
-            if piped is not None:
-                self.voxel_data = piped[1]                       # downloaded piece by piece while the stack was going up
-                _devcache.put(self.voxel_data, vol)
-            else:
-                self.voxel_data = to_host_volume(vol)
+            self.voxel_data = to_host_volume(vol)
         else:
             stacked = np.stack(mask_images, axis=0)          # the reference returns a new array here
             vol = cached if cached is not None else upload_volume(stacked)
