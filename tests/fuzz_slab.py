@@ -56,22 +56,32 @@ def run(seed=0, cases=20):
         refs = [refs[0], refs[0], refs[1]]
         out = [[None] * world for _ in volumes]
         stats, errs = [None] * world, []
-        bar = threading.Barrier(world)
 
         def target(c):
             try:
                 job = slab.SlabJob(nz, ny, nx, c)
                 with torch.cuda.stream(torch.cuda.Stream()):
-                    for p, w in enumerate(volumes):
-                        mask = torch.from_numpy(np.ascontiguousarray(w[job.z0:job.z1]).view(np.uint8)).to(dev)
-                        verts, faces = job.run(mask, depths, my, mx)
-                        torch.cuda.current_stream().synchronize()
-                        out[p][c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.n_vertices_global)
-                        bar.wait()
+                    masks = [torch.from_numpy(np.ascontiguousarray(w[job.z0:job.z1]).view(np.uint8)).to(dev) for w in volumes]
+                    pend = None
+                    for p in range(len(volumes) + 1):
+                        # odd cases: pass p + 1 is submitted BEFORE the host reads pass p (SlabJob.submit / result)
+                        nxt = job.submit(masks[p], depths, my, mx) if p < len(volumes) else None
+                        if not it % 2 and nxt is not None:
+                            job.result(nxt)
+                            got = (p, job.mesh)
+                        elif it % 2 and pend is not None:
+                            job.result(pend[1])
+                            got = (pend[0], job.mesh)
+                        else:
+                            got = None
+                        pend = (p, nxt) if nxt is not None else None
+                        if got is not None:
+                            verts, faces = got[1]
+                            torch.cuda.current_stream().synchronize()
+                            out[got[0]][c.rank] = (verts.cpu().numpy(), faces.cpu().numpy(), job.n_vertices_global)
                 stats[c.rank] = (job.deferred_passes, job.deferred_redone)
             except BaseException as e:   # noqa: BLE001
                 errs.append(e)
-                bar.abort()
                 raise
 
         ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(world)]
