@@ -83,8 +83,9 @@ def test_rank_supervisor_relays_the_worker_and_retries_after_a_hang():
     assert len(lines) == 1 and json.loads(lines[0])["comm"]["backend"] == "nccl", lines
 
 
-def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
-    """bench.py --gpus 2 --backend gloo: two rank PROCESSES sharing this GPU, halos staged through the host -- the whole
+@pytest.mark.parametrize("world,supervised", [(2, True), (3, False)])
+def test_rank_processes_over_gloo_give_the_single_gpu_mesh(world, supervised):
+    """bench.py --gpus N --backend gloo: N rank PROCESSES sharing this GPU (three: a rank with BOTH neighbours), halos staged through the host -- the whole
     multi-rank code path of the bench (self-launch, process group, TorchDistComm, preflight, one-exchange front, deferred
     numbering) except the transport; the mesh they report must have the size of the single-GPU mesh of the same stack."""
     if not torch.cuda.is_available():
@@ -93,22 +94,23 @@ def test_two_rank_processes_over_gloo_give_the_single_gpu_mesh():
     import numpy as np
     from tomography_3d_reconstructor_amd import pipeline
     nzr, ny, nx = 160, 96, 128
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", str(nzr), str(ny), str(nx),
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--size", str(nzr), str(ny), str(nx),
            "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TOMO_BENCH_WORKER")}
     # TOMO_BENCH_SUPERVISE=1: every rank process is a supervisor around a worker child, as under an `nccl` launch -- the real
     # process tree (self-launch -> torch.distributed.run -> rank supervisors -> workers), environment and output relayed
-    env["TOMO_BENCH_SUPERVISE"] = "1"
+    if supervised:
+        env["TOMO_BENCH_SUPERVISE"] = "1"
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["comm"]["ranks"] == 2 and d["comm"]["backend"] == "gloo"
+    assert d["n_gpus"] == world and d["comm"]["ranks"] == world and d["comm"]["backend"] == "gloo"
     from tomography_3d_reconstructor_amd import slab
     deferred = slab.DEFERRED_NUMBERING and pipeline.MC3 and pipeline.NA_HINTS            # (A/B switches of the environment)
     assert d["comm"]["numbering"]["redone"] == 0 and (d["comm"]["numbering"]["deferred_passes"] >= 3) == bool(deferred)
     if deferred and pipeline.PACK_CLOSE_FUSED:
         assert d["comm"]["comm_calls_per_pass_per_rank"] == (4.0 if slab.SPLIT_PACK else 5.0)
     dev = torch.device("cuda:0")
-    mask = pipeline.ellipsoid_mask(2 * nzr, ny, nx, dev).view(torch.uint8)
-    v, f = pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(2 * nzr, 1.0), 1.0, 1.0)
+    mask = pipeline.ellipsoid_mask(world * nzr, ny, nx, dev).view(torch.uint8)
+    v, f = pipeline.extract_surface(pipeline.smooth(pipeline.pack_closed(mask), 3, True), np.full(world * nzr, 1.0), 1.0, 1.0)
     assert (d["config"]["n_vertices"], d["config"]["n_faces"]) == (v.shape[0], f.shape[0])
