@@ -101,7 +101,10 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #define ST4C ST4_NT     // constant tiles: whole-line streams nobody reads back soon
 #define ST4M ST4_PL     // mixed tiles: marching cubes reads exactly these lines next
 template <bool FROM_BITS>
-__global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
+#ifndef FT_MINW
+#define FT_MINW 1       // experiment (round 3): minimum waves per SIMD the register allocation must allow
+#endif
+__global__ __launch_bounds__(FT_THREADS, FT_MINW) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
                                                                 const FieldParams p)
 {
     __shared__ double s_lut[18];
