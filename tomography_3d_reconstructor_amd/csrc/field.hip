@@ -35,9 +35,7 @@
 
 #define FT_ROWS 16                  // rows of a tile = rows of a block
 #define FT_SROWS (FT_ROWS + 4)      // staged rows
-#ifndef FT_ZG
-#define FT_ZG 4                     // slices of a block
-#endif
+#define FT_ZG 4                     // slices of a block (2 / 3 / 5 / 6 / 8 measured slower: DESIGN 4.1)
 #define FT_SLOTS (FT_ZG + 4)        // staged slices
 #define FT_THREADS 256
 #define FT_MAXT 64                  // tiles of a block along x (wider rows: several blocks)
@@ -101,10 +99,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #define ST4C ST4_NT     // constant tiles: whole-line streams nobody reads back soon
 #define ST4M ST4_PL     // mixed tiles: marching cubes reads exactly these lines next
 template <bool FROM_BITS>
-#ifndef FT_MINW
-#define FT_MINW 1       // experiment (round 3): minimum waves per SIMD the register allocation must allow
-#endif
-__global__ __launch_bounds__(FT_THREADS, FT_MINW) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
+__global__ __launch_bounds__(FT_THREADS) void field_tile_kernel(const u32 *__restrict__ ext32, float *__restrict__ field,
                                                                 const FieldParams p)
 {
     __shared__ double s_lut[18];
@@ -126,27 +121,11 @@ __global__ __launch_bounds__(FT_THREADS, FT_MINW) void field_tile_kernel(const u
     FT_STAMP(0);
     // ---- which part of the field is this block's
     if (p.list != nullptr && blockIdx.x >= *p.count) return;
-#ifndef FT_ORDER
-#define FT_ORDER 0      // experiment (round 3): which part of the field a block index names.  0: x chunk, tile row, slice group
-#endif                  // (consecutive blocks = consecutive tile rows of one slice group); 1: slice group fastest; 2: every XCD (block
-                        // index mod 8) takes a contiguous eighth of the regions
-    unsigned lin = p.list != nullptr ? p.list[blockIdx.x] : blockIdx.x;
-    const unsigned nreg = (unsigned)p.nxc * (unsigned)p.ntr * (unsigned)p.nzg;
-    if (FT_ORDER == 2 && p.list == nullptr) {
-        const unsigned per = (nreg + 7u) / 8u, x = lin & 7u, k = lin >> 3;
-        lin = x * per + k;
-        if (k >= per || lin >= nreg) return;
-    }
-    int bx, tr, zg;
-    if (FT_ORDER == 1 && p.list == nullptr) {
-        zg = (int)(lin % (unsigned)p.nzg);
-        tr = (int)((lin / (unsigned)p.nzg) % (unsigned)p.ntr);
-        bx = (int)(lin / ((unsigned)p.nzg * (unsigned)p.ntr));
-    } else {
-        bx = (int)(lin % (unsigned)p.nxc);
-        tr = (int)((lin / (unsigned)p.nxc) % (unsigned)p.ntr);
-        zg = (int)(lin / ((unsigned)p.nxc * (unsigned)p.ntr));
-    }
+    // consecutive blocks = consecutive tile rows of one slice group (other orders measured slower: DESIGN 4.5)
+    const unsigned lin = p.list != nullptr ? p.list[blockIdx.x] : blockIdx.x;
+    const int bx = (int)(lin % (unsigned)p.nxc);
+    const int tr = (int)((lin / (unsigned)p.nxc) % (unsigned)p.ntr);
+    const int zg = (int)(lin / ((unsigned)p.nxc * (unsigned)p.ntr));
     // tiles j0 .. j0+nt-1; chunk boundaries fall on marching-cubes segment boundaries ((j + 7) % 8 == 0) and the
     // chunks of a wide row are equally long (p.tp positions each)
     const int j0 = bx == 0 ? 0 : p.tp * bx - 7;
@@ -697,7 +676,6 @@ TOMO_API int tomo_field_fill(const uint64_t *ext, float *field, int nz, int ny, 
         return tomo_status();
     }
     int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg;
-    if (FT_ORDER == 2) blocks = (blocks + 7) / 8 * 8;
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(field_tile_kernel<false>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, s, (const u32 *)ext, field, p);
     return tomo_status();
@@ -714,7 +692,6 @@ TOMO_API int tomo_field_fill_bits(const uint64_t *bits, float *field, int nz, in
     FieldParams p;
     size_t lds = fill_params(p, nz, ny, nx, pad, signs, gcls);
     int64_t blocks = (int64_t)p.nxc * p.ntr * p.nzg;
-    if (FT_ORDER == 2) blocks = (blocks + 7) / 8 * 8;
     if (blocks > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(field_tile_kernel<true>, dim3((unsigned)blocks), dim3(FT_THREADS), lds, (hipStream_t)stream,
                        (const u32 *)bits, field, p);
