@@ -54,6 +54,13 @@ int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_
 int tomo_host_touch(void *h_data, int64_t nbytes, int nthreads);
 /* np.stack (voxel_processor.py:46) on `nthreads` threads: h_dst[i * bytes_each ..] = the bytes_each bytes at h_src[i]. */
 int tomo_host_gather(const void *const *h_src, int64_t n, int64_t bytes_each, void *h_dst, int nthreads);
+/* SHA-256 with a caller-held, relocatable 112-byte state (ABI 6): the digest of a Z-slab job's WHOLE vertex / face list -- the
+ * bytes one np.unique-numbered mesh holds (surface_extractor.py:115-126) -- is formed rank after rank, the state travels
+ * between the rank processes instead of the lists.  impl: 0 = fastest available (x86 SHA extensions), 1 = portable code.
+ * digest: of everything hashed so far; the state is not changed. */
+int tomo_host_sha256_init(void *h_state112);
+int tomo_host_sha256_update(void *h_state112, const void *h_data, int64_t nbytes, int impl);
+int tomo_host_sha256_digest(const void *h_state112, uint8_t *h_digest32);
 
 /* ---------------------------------------------------------------- geometry helpers (host, pure) */
 int64_t tomo_words_per_row(int nx);                      /* ceil(nx / 64) */

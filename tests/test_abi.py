@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.tomo_abi_version() == 5
+    assert L.tomo_abi_version() == 6
     assert L.tomo_error_string(0) == b"ok"
     assert b"argument" in L.tomo_error_string(-1)
 
@@ -103,7 +103,10 @@ def test_devcache_never_returns_a_stale_volume(monkeypatch):
     from tomography_3d_reconstructor_amd import _devcache
     _devcache.clear()
     v = object()
-    # (1) hand-outs are write-protected: trusted while protected, dropped once the caller made them writeable
+    assert _devcache._writeable_default({}) is True                              # the reference's semantics by default
+    assert _devcache._writeable_default({"TOMO_READONLY_RESULTS": "1"}) is False and _devcache._writeable_default({"TOMO_WRITEABLE_RESULTS": "0"}) is False
+    # (1) TOMO_READONLY_RESULTS: hand-outs are write-protected: trusted while protected, dropped once the caller made them writeable
+    monkeypatch.setattr(_devcache, "WRITEABLE_RESULTS", False)
     big = np.ones((128, 128, 128), bool)
     _devcache.put(big, v)
     assert not big.flags.writeable and _devcache.get(big) is v
@@ -125,7 +128,7 @@ def test_devcache_never_returns_a_stale_volume(monkeypatch):
     _devcache.put(mine2, v, protect=False)
     mine2.reshape(-1)[12345] = False
     assert _devcache.get(mine2) is None
-    # (3) TOMO_WRITEABLE_RESULTS: results stay writeable like the reference's, every lookup verifies
+    # (3) the default: results stay writeable like the reference's, every lookup verifies
     monkeypatch.setattr(_devcache, "WRITEABLE_RESULTS", True)
     res = np.zeros((128, 128, 128), bool)
     _devcache.put(res, v)
@@ -135,3 +138,35 @@ def test_devcache_never_returns_a_stale_volume(monkeypatch):
     # (4) a different object with the same content is not the cached one
     assert _devcache.get(np.ones((128, 128, 128), bool)) is None
     _devcache.clear()
+
+
+def test_host_sha256_with_a_relocatable_state_matches_hashlib():
+    """tomo_host_sha256_*: FIPS 180-4 with a caller-held 112-byte state that can be copied / sent between updates (the Z-slab
+    job hashes its whole mesh rank after rank).  Both implementations (x86 SHA extensions where present, portable) against
+    hashlib, fed in ragged pieces, with the state moved to another buffer in between."""
+    import hashlib
+    import numpy as np
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for impl in (0, 1):
+        for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 70001):
+            data = rng.integers(0, 256, n, dtype=np.uint8)
+            st = np.zeros(112, np.uint8)
+            assert L.tomo_host_sha256_init(st.ctypes.data) == 0
+            pos = 0
+            while pos < n:
+                k = min(int(rng.integers(1, 300)), n - pos)
+                assert L.tomo_host_sha256_update(st.ctypes.data, data[pos:pos + k].ctypes.data, k, impl) == 0
+                st = np.frombuffer(st.tobytes(), np.uint8).copy()               # the state is plain bytes
+                pos += k
+            d = np.zeros(32, np.uint8)
+            assert L.tomo_host_sha256_digest(st.ctypes.data, d.ctypes.data) == 0
+            assert d.tobytes().hex() == hashlib.sha256(data.tobytes()).hexdigest(), (impl, n)
+            d2 = np.zeros(32, np.uint8)                                         # digest() leaves the state usable
+            L.tomo_host_sha256_update(st.ctypes.data, data.ctypes.data if n else None, n, impl)
+            L.tomo_host_sha256_digest(st.ctypes.data, d2.ctypes.data)
+            assert d2.tobytes().hex() == hashlib.sha256(data.tobytes() * 2).hexdigest()
+    assert L.tomo_host_sha256_init(None) == -1 and L.tomo_host_sha256_update(None, None, 0, 0) == -1
+    st = np.zeros(112, np.uint8)
+    L.tomo_host_sha256_init(st.ctypes.data)
+    assert L.tomo_host_sha256_update(st.ctypes.data, None, 5, 0) == -1 and L.tomo_host_sha256_digest(st.ctypes.data, None) == -1

@@ -71,14 +71,34 @@ def test_rank_supervisor_retries_once_over_the_process_group():
             return codes.pop(0)
         return run
     env = {"RANK": "3", "WORLD_SIZE": "8", "MASTER_PORT": "29511", "TORCHELASTIC_USE_AGENT_STORE": "True"}
-    assert bench.supervise(["x"], env, fake([4, 0])) == 0
+    assert bench.supervise(["x"], env, fake([4, 0]), port_wait_s=0.1) == 0       # (rank 0 never published: the old + 1)
     assert len(calls) == 2 and calls[0][1]["TOMO_BENCH_WORKER"] == "1" and "TOMO_RCCL_DIRECT" not in calls[0][1]
     assert calls[1][1]["TOMO_RCCL_DIRECT"] == "0" and calls[1][1]["MASTER_PORT"] == "29512"
     assert "TORCHELASTIC_USE_AGENT_STORE" not in calls[1][1] and calls[1][1]["TOMO_BENCH_WORKER"] == "1"
     del calls[:]
-    assert bench.supervise(["x"], env, fake([4, 4])) == 4 and len(calls) == 2          # one retry, not a loop
+    assert bench.supervise(["x"], env, fake([4, 4]), port_wait_s=0.1) == 4 and len(calls) == 2          # one retry, not a loop
     del calls[:]
     assert bench.supervise(["x"], env, fake([1])) == 1 and len(calls) == 1             # a crash is not a hang
     del calls[:]
     assert bench.supervise(["x"], dict(env, TOMO_RCCL_DIRECT="0"), fake([4])) == 4 and len(calls) == 1   # nothing left to fall back to
     assert env == {"RANK": "3", "WORLD_SIZE": "8", "MASTER_PORT": "29511", "TORCHELASTIC_USE_AGENT_STORE": "True"}
+
+
+def test_retry_port_is_probed_by_rank_0_and_shared():
+    """the retry's rendezvous port is one rank 0's supervisor found FREE, and every other rank's supervisor (same
+    agent, same node) reads that very port instead of assuming MASTER_PORT + 1."""
+    import socket
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0))
+    busy.listen(1)
+    base = busy.getsockname()[1] - 1                       # MASTER_PORT + 1 is taken
+    env0 = {"RANK": "0", "MASTER_PORT": str(base), "TORCHELASTIC_RUN_ID": "t%d" % os.getpid()}
+    try:
+        p0 = bench.retry_port(env0)
+        assert p0 > base + 1                               # skipped the busy one
+        s = socket.socket()
+        s.bind(("127.0.0.1", p0))                          # and it is free
+        s.close()
+        assert bench.retry_port(dict(env0, RANK="5"), wait_s=5.0) == p0
+    finally:
+        busy.close()

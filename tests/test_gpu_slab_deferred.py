@@ -334,3 +334,22 @@ def test_extract_surface_submit_reads_one_pass_late(dev):
     assert plain[-1] is None and got[-1] is None
     for p, g in zip(plain[:-1], got[:-1]):
         assert torch.equal(p[0], g[0]) and torch.equal(p[1], g[1])
+
+
+def test_host_waits_of_a_multi_rank_pass_have_a_deadline():
+    """RCCL's C API has no timeout and its calls sit in the compute stream, so every host wait of a multi-rank pass goes
+    through pipeline.wait_event: a stream that does not get there in time becomes a TomoError instead of a hang."""
+    import time
+    from tomography_3d_reconstructor_amd import _lib
+    dev = torch.device("cuda:0")
+    t = torch.arange(8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(1.5e9))                      # ~0.6-1 s of a spinning kernel in front of the copy
+    pend = pipeline.PendingDownload(t)
+    t0 = time.monotonic()
+    with pytest.raises(_lib.TomoError, match="did not arrive"):
+        pipeline.wait_event(pend._event, 0.05, "the counters of a pass")
+    assert time.monotonic() - t0 < 0.5
+    assert pend.wait(30.0) == list(range(8))           # with a sane deadline the same download simply arrives
+    job = slab.SlabJob(64, 32, 64, type("C", (), {"rank": 0, "world": 2})())
+    job._await(dev)                                    # an idle stream: returns at once

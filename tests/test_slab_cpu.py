@@ -48,7 +48,7 @@ def run_rank(comm, v, depths, mm_y, mm_x, out, obj_path=None):
     # the consumers named in BASELINE configs[3] / [4]: one OBJ from all ranks, VolumeCalculator numbers of the whole stack
     extras = {"vol_s": job.voxel_volume(mm_x, mm_y, depths), "vol_c": job.voxel_volume(mm_x, mm_y, depths, "created"),
               "box_s": job.bounding_box(mm_x, mm_y, depths), "box_c": job.bounding_box(mm_x, mm_y, depths, "created"),
-              "counts": job.slice_counts()}
+              "counts": job.slice_counts(), "sha": job.mesh_sha256()}
     if obj_path is not None:
         extras["obj_bytes"] = job.export_obj(obj_path, nthreads=2)
     out[comm.rank] += (extras,)
@@ -84,6 +84,13 @@ def check(out, ref):
     assert out[0][3] == len(rv)
     assert verts.shape == rv.shape and verts.tobytes() == rv.tobytes()
     assert faces.shape == rf.shape and np.array_equal(faces, rf)
+    # the digest of the WHOLE mesh, formed rank after rank without gathering it (SlabJob.mesh_sha256): every rank reports the
+    # SHA-256 of the single-rank arrays
+    import hashlib
+    want = (hashlib.sha256(rv.tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(rf, np.int64).tobytes()).hexdigest(), len(rv), len(rf))
+    for r in range(world):
+        if len(out[r]) > 4 and "sha" in out[r][4]:
+            assert tuple(out[r][4]["sha"]) == want, (r, out[r][4]["sha"], want)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -129,7 +136,7 @@ def _gloo_worker(rank, world, port, shape, seed, tmpdir):
         assert comm.stats["calls"] > 0 and comm.stats["bytes_sent"] > 0
         ex = out[rank][4]
         np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), v=out[rank][0], f=out[rank][1], off=out[rank][2],
-                 nvg=out[rank][3], counts=ex["counts"], vol_s=ex["vol_s"], vol_c=ex["vol_c"], obj_bytes=ex["obj_bytes"],
+                 nvg=out[rank][3], sha=np.array(list(map(str, ex["sha"]))), counts=ex["counts"], vol_s=ex["vol_s"], vol_c=ex["vol_c"], obj_bytes=ex["obj_bytes"],
                  box_s=np.asarray([*ex["box_s"]["x"], *ex["box_s"]["y"], *ex["box_s"]["z"], *ex["box_s"]["dimensions"]], np.float64),
                  box_c=np.asarray([*ex["box_c"]["x"], *ex["box_c"]["y"], *ex["box_c"]["z"], *ex["box_c"]["dimensions"]], np.float64))
     finally:
@@ -151,7 +158,7 @@ def test_slab_gloo_processes_match_single_rank(world, tmp_path):
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         out.append((d["v"], d["f"], int(d["off"]), int(d["nvg"]),
-                    {"counts": d["counts"], "vol_s": d["vol_s"], "vol_c": d["vol_c"], "obj_bytes": int(d["obj_bytes"]),
+                    {"sha": tuple(x if i < 2 else int(x) for i, x in enumerate(d["sha"].tolist())), "counts": d["counts"], "vol_s": d["vol_s"], "vol_c": d["vol_c"], "obj_bytes": int(d["obj_bytes"]),
                      "box_s": box(d["box_s"]), "box_c": box(d["box_c"])}))
     check(out, ref)
     check_consumers(out, v, np.full(shape[0], 0.5), 1.0, 1.0, os.path.join(str(tmp_path), "slab.obj"))

@@ -6,13 +6,14 @@ bit-packed device copy is remembered against the returned ndarray.  The referenc
 (voxel_processor.py:84, surface_extractor.py:43-46), so a cached copy is used ONLY when the array provably still holds
 what was uploaded:
 
-  * arrays this package returns are handed out READ-ONLY (`flags.writeable = False`; nothing in the reference writes
-    into a volume it got back -- its consumers only read).  While the flag is still clear the content cannot have been
-    changed through the array or any view of it: the cached copy is exact, at no cost.
-  * an array that is writeable at lookup (the caller set the flag, or TOMO_WRITEABLE_RESULTS=1 asks for writeable
-    results like the reference's) may have been edited: every byte is checked -- a position-dependent 128-bit checksum
-    over the whole array (native, threaded: tomo_host_checksum) against the one taken when the device copy was made --
-    and any difference, or no stored checksum, drops the entry and the array is uploaded again.
+  * DEFAULT (round 4; the reference's array semantics: voxel_processor.py:58, :84 return fresh WRITEABLE arrays): results are
+    ordinary writeable arrays.  An array that is writeable at lookup may have been edited, so every byte is checked -- a
+    position-dependent 128-bit checksum over the whole array (native, threaded: tomo_host_checksum, ~5 ms per GiB on the GPU
+    host) against the one taken when the device copy was made -- and any difference, or no stored checksum, drops the entry
+    and the array is uploaded again.
+  * OPT-IN fast path, TOMO_READONLY_RESULTS=1 (rounds 1-3's default): results are handed out READ-ONLY
+    (`flags.writeable = False`; nothing in the reference writes into a volume it got back).  While the flag is still clear
+    the content cannot have been changed through the array or any view of it: the cached copy is exact, at no cost.
 
 There is no sampling anywhere: a hit is either write-protected or fully verified.
 """
@@ -27,7 +28,17 @@ from . import _lib
 
 _MAX = 8          # entries hold bit-packed device volumes (1 bit per voxel); repeated results share one
 _cache = OrderedDict()
-WRITEABLE_RESULTS = os.environ.get("TOMO_WRITEABLE_RESULTS", "0") not in ("", "0")
+
+
+def _writeable_default(env=os.environ):
+    """Writeable results unless TOMO_READONLY_RESULTS=1 (or the older spelling TOMO_WRITEABLE_RESULTS=0) asks for the
+    write-protected fast path."""
+    if env.get("TOMO_READONLY_RESULTS", "0") not in ("", "0"):
+        return False
+    return env.get("TOMO_WRITEABLE_RESULTS", "1") not in ("", "0")
+
+
+WRITEABLE_RESULTS = _writeable_default()
 STATS = {"hit_readonly": 0, "hit_verified": 0, "miss_edited": 0, "miss_unverifiable": 0}
 
 
@@ -47,7 +58,7 @@ def _layout(arr):
 
 def put(arr, vol, protect=True):
     """Remember `vol` as the device copy of `arr`'s CURRENT content.  protect=True (arrays this package creates and
-    returns) write-protects the array; otherwise -- and always under TOMO_WRITEABLE_RESULTS -- its checksum is stored."""
+    returns) write-protects the array under TOMO_READONLY_RESULTS; otherwise -- the default -- its checksum is stored."""
     if not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous:
         return
     key = id(arr)

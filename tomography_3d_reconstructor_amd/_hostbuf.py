@@ -44,17 +44,45 @@ def _purge(now):
             del _reserved[n]
 
 
+_timer = [None]
+
+
+def _purge_later():
+    """Stale reservations are dropped by a timer, not by whoever calls next: a process that reserved and never came back (a
+    create_voxel_data without the smooth_voxel_data that usually follows) must not keep volume-sized arrays resident."""
+    with _lock:
+        _timer[0] = None
+        _purge(time.monotonic())
+        again = bool(_reserved)
+    if again:
+        _arm_timer()
+
+
+def _arm_timer():
+    with _lock:
+        if _timer[0] is None and _reserved:
+            t = _timer[0] = threading.Timer(STALE_S + 0.5, _purge_later)
+            t.daemon = True
+            t.start()
+
+
+MAX_RESERVE = int(os.environ.get("TOMO_HOSTBUF_MAX", str(16 << 30)))   # bytes of reservations in flight at most (beyond: take() allocates)
+
+
 def reserve(nbytes, count=1):
     """Start paging `count` arrays of `nbytes` in, in the background, for take() calls that will follow shortly."""
     global _pool
     now = time.monotonic()
     with _lock:
         _purge(now)
+        held = sum(n * len(v) for n, v in _reserved.items())
+        count = min(count, len(_reserved.get(int(nbytes), [])) + max(0, (MAX_RESERVE - held) // max(int(nbytes), 1)))
         if _pool is None:
             _pool = ThreadPoolExecutor(2, thread_name_prefix="tomo-hostbuf")
         have = len(_reserved.get(int(nbytes), []))
         for _ in range(max(0, count - have)):
             _reserved.setdefault(int(nbytes), []).append((now, _pool.submit(_fresh, nbytes)))
+    _arm_timer()
 
 
 def take(shape, dtype):

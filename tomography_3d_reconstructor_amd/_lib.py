@@ -28,6 +28,9 @@ SIGNATURES = {
     "tomo_host_checksum": (_c_i, [_c_p, _c_i64, _c_i, _c_p]),
     "tomo_host_touch": (_c_i, [_c_p, _c_i64, _c_i]),
     "tomo_host_gather": (_c_i, [_c_p, _c_i64, _c_i64, _c_p, _c_i]),
+    "tomo_host_sha256_init": (_c_i, [_c_p]),
+    "tomo_host_sha256_update": (_c_i, [_c_p, _c_p, _c_i64, _c_i]),
+    "tomo_host_sha256_digest": (_c_i, [_c_p, _c_p]),
     "tomo_words_per_row": (_c_i64, [_c_i]),
     "tomo_ext_words_per_row": (_c_i64, [_c_i, _c_i]),
     "tomo_ext_rows": (_c_i64, [_c_i, _c_i]),

@@ -6,6 +6,7 @@
 // Reference lines replaced: voxel_processor.py:46 (stack), :51 (np.sum), :56-77 (close ends),
 // :79-97 (binary_opening + binary_closing with the 3-D cross, erosion border_value=True).
 #include <stdlib.h>
+#include <atomic>
 #include "tomo_common.h"
 
 // ------------------------------------------------------------------------------------------
@@ -731,20 +732,26 @@ static inline int fill_bands_plan(int ny, int wx, int *RB_out)
 // answer is cached per LDS size.)  Occupancy per CU x CUs -- on a partitioned or smaller part the one-workgroup kernel runs.
 static bool fill_bands_fit(int blocks, size_t lds_bytes)
 {
-    static size_t cached_lds = 0;
-    static int cached_capacity = -1, cached_dev = -1;
+    // one slot per device; a slot packs (LDS bytes << 20 | capacity + 1) into ONE atomic word, so concurrent callers (the rank
+    // threads of a rehearsed slab job, one device each) either see a complete entry or recompute it -- no torn state
+    static std::atomic<uint64_t> cache[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (cached_capacity < 0 || cached_lds != lds_bytes || cached_dev != dev) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fill_holes_bands_kernel, FB_THREADS, lds_bytes) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        cached_capacity = per_cu * cus; cached_lds = lds_bytes; cached_dev = dev;
+    const bool slot = dev >= 0 && dev < 64 && lds_bytes < ((size_t)1 << 40);
+    if (slot) {
+        const uint64_t e = cache[dev].load(std::memory_order_relaxed);
+        if (e != 0 && (e >> 20) == (uint64_t)lds_bytes) return blocks <= (int)(e & 0xFFFFF) - 1;
     }
-    return blocks <= cached_capacity;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fill_holes_bands_kernel, FB_THREADS, lds_bytes) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int capacity = per_cu * cus;
+    if (capacity > 0xFFFFE) capacity = 0xFFFFE;
+    if (slot) cache[dev].store(((uint64_t)lds_bytes << 20) | (uint64_t)(capacity + 1), std::memory_order_relaxed);
+    return blocks <= capacity;
 }
 
 static int fill_holes_launch(u64 *sliceA, u64 *sliceB, int ny, int nx, int wx, u64 *scratch, hipStream_t st,

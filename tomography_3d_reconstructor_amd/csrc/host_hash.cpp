@@ -11,6 +11,9 @@
 #include <string.h>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "../../include/tomo_hip.h"
 
 #define TOMO_API extern "C" __attribute__((visibility("default")))
@@ -171,5 +174,165 @@ TOMO_API int tomo_host_gather(const void *const *h_src, int64_t n, int64_t bytes
         }
         for (auto &t : th) t.join();
     }
+    return TOMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SHA-256 (FIPS 180-4) with a caller-held, RELOCATABLE state.  hashlib cannot hand a running hash to another process; the
+// Z-slab job needs exactly that: the digest of the WHOLE vertex / face list -- the bytes a single-GPU run returns, what
+// the golden fixtures hold (the reference numbers its vertices globally: surface_extractor.py:115-126) -- without gathering
+// the lists: rank 0 hashes its rows, the 112-byte state travels to rank 1, which continues with its rows, ...
+// (slab.SlabJob.mesh_sha256).  State layout (little endian): u32 h[8] | u64 total bytes | u32 bytes buffered | u32 0 |
+// u8 buffer[64].  A portable implementation plus the x86 SHA extensions where the CPU has them (same results).
+namespace {
+
+struct Sha256State {
+    uint32_t h[8];
+    uint64_t nbytes;
+    uint32_t buflen, pad;
+    uint8_t buf[64];
+};
+static_assert(sizeof(Sha256State) == 112, "state layout is part of the ABI");
+
+const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+inline uint32_t rotr32(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+
+void sha256_blocks_portable(uint32_t h[8], const uint8_t *p, int64_t nblocks)
+{
+    for (; nblocks > 0; nblocks--, p += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++)
+            w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | (uint32_t)p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25), ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + SHA_K[i] + w[i];
+            const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22), maj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t t2 = S0 + maj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("sha,sse4.1,ssse3"))) void sha256_blocks_shani(uint32_t h[8], const uint8_t *p, int64_t nblocks)
+{
+    const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    __m128i tmp = _mm_loadu_si128((const __m128i *)&h[0]);          // DCBA
+    __m128i st1 = _mm_loadu_si128((const __m128i *)&h[4]);          // HGFE
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                             // CDAB
+    st1 = _mm_shuffle_epi32(st1, 0x1B);                             // EFGH
+    __m128i st0 = _mm_alignr_epi8(tmp, st1, 8);                     // ABEF
+    st1 = _mm_blend_epi16(st1, tmp, 0xF0);                          // CDGH
+    for (; nblocks > 0; nblocks--, p += 64) {
+        const __m128i save0 = st0, save1 = st1;
+        __m128i m[4], msg;
+        for (int i = 0; i < 4; i++) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * i)), MASK);
+        for (int r = 0; r < 16; r++) {                              // 16 groups of 4 rounds
+            __m128i cur = m[r & 3];
+            msg = _mm_add_epi32(cur, _mm_loadu_si128((const __m128i *)&SHA_K[4 * r]));
+            st1 = _mm_sha256rnds2_epu32(st1, st0, msg);
+            msg = _mm_shuffle_epi32(msg, 0x0E);
+            st0 = _mm_sha256rnds2_epu32(st0, st1, msg);
+            if (r < 12) {                                           // schedule w[4 (r + 4) .. 4 (r + 4) + 3] into m[r & 3]
+                __m128i x = _mm_sha256msg1_epu32(m[r & 3], m[(r + 1) & 3]);
+                x = _mm_add_epi32(x, _mm_alignr_epi8(m[(r + 3) & 3], m[(r + 2) & 3], 4));
+                m[r & 3] = _mm_sha256msg2_epu32(x, m[(r + 3) & 3]);
+            }
+        }
+        st0 = _mm_add_epi32(st0, save0);
+        st1 = _mm_add_epi32(st1, save1);
+    }
+    tmp = _mm_shuffle_epi32(st0, 0x1B);                             // FEBA
+    st1 = _mm_shuffle_epi32(st1, 0xB1);                             // DCHG
+    st0 = _mm_blend_epi16(tmp, st1, 0xF0);                          // DCBA
+    st1 = _mm_alignr_epi8(st1, tmp, 8);                             // HGFE
+    _mm_storeu_si128((__m128i *)&h[0], st0);
+    _mm_storeu_si128((__m128i *)&h[4], st1);
+}
+bool have_shani()
+{
+    static const bool yes = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+    return yes;
+}
+#endif
+
+void sha256_blocks(uint32_t h[8], const uint8_t *p, int64_t nblocks, int impl)
+{
+#if defined(__x86_64__)
+    if (impl != 1 && have_shani()) { sha256_blocks_shani(h, p, nblocks); return; }
+#endif
+    sha256_blocks_portable(h, p, nblocks);
+}
+
+}  // namespace
+
+// state: 112 bytes the caller holds (any alignment; may be copied, stored, sent to another process between calls).
+TOMO_API int tomo_host_sha256_init(void *h_state)
+{
+    if (!h_state) return TOMO_E_ARG;
+    Sha256State s;
+    memset(&s, 0, sizeof s);
+    const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(s.h, iv, sizeof iv);
+    memcpy(h_state, &s, sizeof s);
+    return TOMO_OK;
+}
+
+// impl: 0 = the fastest the CPU offers, 1 = the portable code (tests compare the two)
+TOMO_API int tomo_host_sha256_update(void *h_state, const void *h_data, int64_t nbytes, int impl)
+{
+    if (!h_state || nbytes < 0 || (nbytes > 0 && !h_data)) return TOMO_E_ARG;
+    Sha256State s;
+    memcpy(&s, h_state, sizeof s);
+    if (s.buflen >= 64) return TOMO_E_ARG;
+    const uint8_t *p = (const uint8_t *)h_data;
+    int64_t n = nbytes;
+    s.nbytes += (uint64_t)nbytes;
+    if (s.buflen) {
+        const int64_t take = n < 64 - (int64_t)s.buflen ? n : 64 - (int64_t)s.buflen;
+        memcpy(s.buf + s.buflen, p, (size_t)take);
+        s.buflen += (uint32_t)take; p += take; n -= take;
+        if (s.buflen == 64) { sha256_blocks(s.h, s.buf, 1, impl); s.buflen = 0; }
+    }
+    if (n >= 64) {
+        sha256_blocks(s.h, p, n / 64, impl);
+        p += n / 64 * 64; n %= 64;
+    }
+    if (n) { memcpy(s.buf, p, (size_t)n); s.buflen = (uint32_t)n; }
+    memcpy(h_state, &s, sizeof s);
+    return TOMO_OK;
+}
+
+// the digest of everything hashed so far; the state is left as it is (more data may follow)
+TOMO_API int tomo_host_sha256_digest(const void *h_state, uint8_t *h_digest32)
+{
+    if (!h_state || !h_digest32) return TOMO_E_ARG;
+    Sha256State s;
+    memcpy(&s, h_state, sizeof s);
+    if (s.buflen >= 64) return TOMO_E_ARG;
+    uint8_t tail[128];
+    memset(tail, 0, sizeof tail);
+    memcpy(tail, s.buf, s.buflen);
+    tail[s.buflen] = 0x80;
+    const int blocks = s.buflen + 9 <= 64 ? 1 : 2;
+    const uint64_t bits = s.nbytes * 8;
+    for (int i = 0; i < 8; i++) tail[blocks * 64 - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_blocks(s.h, tail, blocks, 1);
+    for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 4; b++) h_digest32[4 * i + b] = (uint8_t)(s.h[i] >> (24 - 8 * b));
     return TOMO_OK;
 }

@@ -10,7 +10,7 @@
 
 #define TOMO_API extern "C" __attribute__((visibility("default")))
 
-TOMO_API int tomo_abi_version(void) { return 5; }
+TOMO_API int tomo_abi_version(void) { return 6; }
 
 TOMO_API const char *tomo_error_string(int code)
 {

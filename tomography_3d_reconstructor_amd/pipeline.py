@@ -663,6 +663,21 @@ def _download_vec(t):
     return host.tolist()
 
 
+def wait_event(event, timeout_s, what="the stream"):
+    """event.synchronize() with a deadline: polls (busy for the first 2 ms -- the usual wait is microseconds -- then in 0.1 ms
+    naps) and raises TomoError after timeout_s seconds."""
+    import time
+    if event.query():
+        return
+    t0 = time.monotonic()
+    while not event.query():
+        dt = time.monotonic() - t0
+        if dt > timeout_s:
+            raise _lib.TomoError("%s did not arrive within %.0f s: the GPU is stuck or a neighbour rank has left the job" % (what, timeout_s))
+        if dt > 2e-3:
+            time.sleep(1e-4)
+
+
 class PendingDownload:
     """A small int64 device vector on its way into page-locked memory: started on the current stream, read by wait().
     Every pending download owns its buffer for as long as it lives (several passes may be in flight), buffers are recycled
@@ -678,8 +693,13 @@ class PendingDownload:
         self._event = torch.cuda.Event()
         self._event.record(torch.cuda.current_stream(t.device))
 
-    def wait(self):
-        self._event.synchronize()
+    def wait(self, timeout_s=None):
+        """timeout_s: give up (TomoError) when the copy has not arrived by then -- for a stream that carries RCCL calls, which
+        have no timeout of their own: a neighbour rank that left the job must become an error here, not a hang."""
+        if timeout_s is None:
+            self._event.synchronize()
+        else:
+            wait_event(self._event, timeout_s, "the counters of a pass")
         out = self._host.tolist()
         PendingDownload._free[self._key].append(self._host)
         self._host = None

@@ -42,6 +42,11 @@ PC_EDGE = 4      # slices at either end of a slab that wait for the neighbours' 
 MERGED_MIN = 128 # slices per rank from which the one-exchange front is used (thinner slabs: the two-exchange front)
 SPLIT_PACK = os.environ.get("TOMO_SLAB_SPLIT", "1") not in ("", "0")              # middle of the slab before the neighbour chain (A/B switch)
 DEFERRED_NUMBERING = os.environ.get("TOMO_SLAB_DEFERRED", "1") not in ("", "0")   # the pass with ONE download (A/B switch)
+# Every host wait of a multi-rank pass has this deadline (seconds; 0 = none).  RCCL's C API has no timeout of its own and the
+# collectives sit in the compute stream: a rank that left the job (an error only IT saw -- e.g. the triangle kernel's
+# missing-vertex count, which exists only after the all-gather of the summaries and so cannot be decided jointly) would leave
+# its neighbours waiting for ever in the next exchange.  With the deadline they raise TomoError instead.
+TIMEOUT_S = float(os.environ.get("TOMO_SLAB_TIMEOUT_S", "300"))
 
 
 # ----------------------------------------------------------------------------- communication
@@ -706,6 +711,14 @@ class SlabJob:
     def _msg_cap(n):
         return int(n * 1.25) + 64
 
+    def _await(self, dev):
+        """Wait for the current stream of `dev` with the job's deadline (TIMEOUT_S) before a host read that follows a collective
+        step: a neighbour that has left becomes a TomoError here instead of a hang inside .cpu()."""
+        if self.world > 1 and TIMEOUT_S and torch.device(dev).type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            pipeline.wait_event(ev, TIMEOUT_S, "a collective step of the slab job")
+
     def _number_rows(self, uniq, slice_depths, dev, ready=False):
         """uniq: this rank's sorted, duplicate-free vertex rows (nu, 3).  -> (the rows this rank keeps, gid int64 (nu,):
         the GLOBAL index of every one of the nu rows).  Sets self.vertex_offset / self.n_vertices_global.
@@ -724,6 +737,7 @@ class SlabJob:
         if not last and nu:
             nt = (uniq[:, 0] == self._z_top(slice_depths, dev)).sum().reshape(1).to(torch.int64)
         cnt_prev, _ = c.exchange(None, nt, torch.int64)
+        self._await(dev)
         pair = torch.cat([nt, cnt_prev.reshape(1) if cnt_prev is not None else torch.zeros_like(nt)]).cpu()
         n_top, n_from_prev = int(pair[0]), int(pair[1])
         k = nu - n_top                                             # rows this rank keeps
@@ -746,7 +760,9 @@ class SlabJob:
         # below that is new to it -- that rank merges the two sorted lists properly, which changes its count, and the counts
         # are gathered once more (rare with the HIP engine: the lower rank's shared-plane rows are this rank's own)
         got = torch.stack(c.all_gather(torch.cat([torch.tensor([k], dtype=torch.int64, device=dev), miss,
-                                                  torch.tensor([1 if ready else 0], dtype=torch.int64, device=dev)]))).cpu()
+                                                  torch.tensor([1 if ready else 0], dtype=torch.int64, device=dev)])))
+        self._await(dev)
+        got = got.cpu()
         counts, misses = [int(x) for x in got[:, 0]], [int(x) for x in got[:, 1]]
         self._deferred_ok = all(int(x) for x in got[:, 2])
         self._cap_top, self._cap_prev = self._msg_cap(n_top), self._msg_cap(n_from_prev)
@@ -854,7 +870,10 @@ class SlabJob:
         r, w = self.rank, self.world
         m, faces, f, Za, slice_depths, z_top, dev = t["m"], t["faces"], t["f"], t["Za"], t["depths"], t["z_top"], t["dev"]
         mm_y, mm_x = t["mm"]
-        host = t["down"].wait() if t["down"] is not None else e.download(t["counters"])
+        if t["down"] is not None:
+            host = t["down"].wait(TIMEOUT_S or None) if w > 1 else t["down"].wait()
+        else:
+            host = e.download(t["counters"])
         own, g = host[:8], [host[8 + 8 * i:16 + 8 * i] for i in range(w)]
         bad = any(row[1] or row[2] for row in g) or any(g[i][4] != g[i + 1][5] for i in range(w - 1))
         if bad:
@@ -945,6 +964,49 @@ class SlabJob:
         """== VolumeCalculator.calculate_bounding_box_variable_depth(whole volume, ...) (volume_calculator.py:59-94)."""
         from .volume_calculator import box_variable_depth
         return box_variable_depth(self.index_box(which), mm_per_pixel_x, mm_per_pixel_y, slice_depths)
+
+    def mesh_sha256(self, mesh=None):
+        """SHA-256 of the WHOLE mesh -- the bytes of the (V, 3) float32 vertex array and of the (F, 3) int64 face array that a
+        single-GPU run of the same stack returns, i.e. what the reference's global np.unique numbering gives
+        (surface_extractor.py:115-126) and what tests/golden/ellipsoid_hashes*.json hold -- WITHOUT gathering the lists: rank 0
+        hashes its rows, the two 112-byte running states travel up the ranks (world - 1 neighbour steps, every rank takes part
+        in each), the last rank's digests come back in one all-gather.  `mesh`: this rank's (vertices, faces) of some pass
+        (default: the job's current one).  -> (vertices hex, faces hex, n_vertices, n_faces) on every rank."""
+        from . import _lib
+        L = _lib.lib()
+        mesh = self.mesh if mesh is None else mesh
+        if mesh is None:
+            raise RuntimeError("run() first")
+        v = np.ascontiguousarray(mesh[0].detach().cpu().numpy(), dtype=np.float32)
+        f = np.ascontiguousarray(mesh[1].detach().cpu().numpy(), dtype=np.int64)
+        dev = mesh[0].device
+        r, w = self.rank, self.world
+        st = np.zeros(224 + 16, dtype=np.uint8)                          # two states + the running (vertices, faces) counts
+        _lib.check(L.tomo_host_sha256_init(st[0:].ctypes.data), "tomo_host_sha256_init")
+        _lib.check(L.tomo_host_sha256_init(st[112:].ctypes.data), "tomo_host_sha256_init")
+
+        def mine(st):
+            _lib.check(L.tomo_host_sha256_update(st[0:].ctypes.data, v.ctypes.data if v.size else None, v.nbytes, 0), "tomo_host_sha256_update")
+            _lib.check(L.tomo_host_sha256_update(st[112:].ctypes.data, f.ctypes.data if f.size else None, f.nbytes, 0), "tomo_host_sha256_update")
+            st[224:].view(np.int64)[:] += (len(v), len(f))
+        if r == 0:
+            mine(st)
+        for step in range(w - 1):                                        # after step k rank k + 1 holds the state of ranks 0 .. k + 1
+            got, _ = self.comm.exchange(None, torch.from_numpy(st.copy()).to(dev), torch.uint8)
+            if r == step + 1:
+                self._await(dev)
+                st = got.cpu().numpy().copy()
+                mine(st)
+        out = np.zeros(64 + 16, dtype=np.uint8)
+        _lib.check(L.tomo_host_sha256_digest(st[0:].ctypes.data, out[0:].ctypes.data), "tomo_host_sha256_digest")
+        _lib.check(L.tomo_host_sha256_digest(st[112:].ctypes.data, out[32:].ctypes.data), "tomo_host_sha256_digest")
+        out[64:] = st[224:]
+        if w > 1:
+            parts = self.comm.all_gather(torch.from_numpy(out).to(dev))
+            self._await(dev)
+            out = parts[w - 1].cpu().numpy()
+        nv, nf = (int(x) for x in out[64:].view(np.int64))
+        return out[:32].tobytes().hex(), out[32:64].tobytes().hex(), nv, nf
 
     def export_obj(self, path, nthreads=None):
         """ONE OBJ file of the whole mesh, byte for byte what OBJExporter.export_to_obj writes from the gathered

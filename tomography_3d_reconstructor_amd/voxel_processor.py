@@ -6,6 +6,7 @@ device copy of every returned volume is cached (see _devcache: returned volumes 
 writeable array is verified byte for byte before its cached copy is used) so the orchestrator's next call does
 not upload it again.  There is no CPU fallback: without a GPU / the built library these methods raise.
 """
+import os
 import sys
 import threading
 
@@ -71,14 +72,34 @@ def to_host_volume(vol):
 
 _STAGE = {}          # the staging array of the last upload, kept for the next one of the same size: a fresh gibibyte costs its
 #                      page faults on the way in AND ~25 ms of munmap on the way out (measured: tools/h2hprof.py)
+_STAGE_LOCK = threading.Lock()
+_STAGE_TIMER = [None]
+STAGE_IDLE_S = 20.0  # ... but not for ever: an idle staging array goes back to the system after this long (a timer, not the
+#                      next call: a process that made its one create_voxel_data must not sit on a volume-sized array)
+STAGE_KEEP_MAX = int(os.environ.get("TOMO_STAGE_KEEP_MAX", str(8 << 30)))   # larger staging arrays are never kept between calls
+
+
+def _release_staging():
+    with _STAGE_LOCK:
+        _STAGE.clear()
+        _STAGE_TIMER[0] = None
 
 
 def _staging(shape):
     key = (threading.get_ident(), tuple(shape))
-    a = _STAGE.get(key)
-    if a is None:
-        _STAGE.clear()                      # one staging array per process: another shape replaces it
-        a = _STAGE[key] = np.empty(shape, dtype=np.bool_)
+    with _STAGE_LOCK:
+        a = _STAGE.get(key)
+        if a is None:
+            _STAGE.clear()                      # one staging array per process: another shape replaces it
+            a = np.empty(shape, dtype=np.bool_)
+            if a.nbytes <= STAGE_KEEP_MAX:
+                _STAGE[key] = a
+        if _STAGE_TIMER[0] is not None:
+            _STAGE_TIMER[0].cancel()
+        if _STAGE:
+            t = _STAGE_TIMER[0] = threading.Timer(STAGE_IDLE_S, _release_staging)
+            t.daemon = True
+            t.start()
     return a
 
 
@@ -87,7 +108,6 @@ def _stage_masks(mask_images):
     threads (NumPy releases the GIL while copying) and uploaded chunk by chunk behind them: (nz, ny, nx) uint8 0/1 on
     the device."""
     from concurrent.futures import ThreadPoolExecutor
-    import os
     first = np.asarray(mask_images[0])
     if first.ndim != 2:
         raise ValueError("all input arrays must have the same shape")          # what np.stack reports for ragged input
@@ -99,7 +119,9 @@ def _stage_masks(mask_images):
     stage = _staging((nz,) + first.shape)
     # uploads in pieces of >= 128 MiB (below that ROCm stages a pageable source through its own buffers at a fraction of the
     # bus rate; above it the source is page-locked on the fly: 1 GiB in 8 pieces 19 ms, in 32 pieces 90-120 ms)
-    per_slice = max(first.size, 1)
+    per_slice = int(first.size)             # bytes per mask (bool); create_voxel_data keeps zero-size stacks away from here
+    if per_slice == 0:
+        raise ValueError("zero-size masks have nothing to stage")
     up = max(1, min(nz, -(-(128 << 20) // per_slice)))                                           # slices per upload piece
     dev = torch.empty((nz,) + first.shape, dtype=torch.bool, device=_device())
     # Fast path (what an image loader produces: separate C-contiguous bool / uint8-of-0/1... arrays of one shape): the
@@ -180,6 +202,12 @@ class VoxelProcessor:
         self.side_0_count = side_0_count
         self.side_1_count = side_1_count
         self.side_2_count = side_2_count
+        if np.asarray(mask_images[0]).size == 0:
+            # masks without a single pixel (shape (0, k) / (k, 0)): nothing to upload, close or count -- np.stack as the reference
+            # does (voxel_processor.py:46; a ragged list raises its ValueError), closing the ends of an empty volume changes nothing
+            self.voxel_data = np.stack(mask_images, axis=0)
+            print(f"Voxels: {self.voxel_data.shape}, active: {int(np.sum(self.voxel_data)):,}")
+            return self.voxel_data
         base = _common_base(mask_images)
         cached = _devcache.get(base) if base is not None else None
         if close_ends and torch.cuda.is_available():
