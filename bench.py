@@ -851,6 +851,7 @@ def run(args, world, cpu=None):
     if not dist and not args.no_extras:
         res = blk["res"] = None
         pipeline._NA_HINT.clear()
+        pipeline._MC3_HINT.clear()
         for k in pipeline.COUNTERS:
             pipeline.COUNTERS[k] = 0
         torch.cuda.synchronize()

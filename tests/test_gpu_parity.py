@@ -934,35 +934,45 @@ def test_one_sort_unique_with_clamped_first_slice(dev, kind):
             assert pipeline.COUNTERS["unique_fallback"] - c0["unique_fallback"] == 0
 
 
-@pytest.mark.parametrize("ny,kind", [(1278, "body"), (1279, "body"), (1400, "body"), (1400, "first"), (1560, "noise")])
+@pytest.mark.parametrize("ny,kind", [(638, "body"), (639, "body"), (1400, "body"), (1400, "wide"), (1400, "first"), (660, "first_thin"), (1560, "noise")])
 def test_planes_sorted_in_bands_of_owner_rows_vs_oracle(dev, ny, kind):
-    """Planes of more than 1280 field rows (ny + 2 with padding) are sorted in bands of 512 owner rows (tomo_common.h:
+    """Planes of more than 640 field rows (ny + 2 with padding) are sorted in bands of 512 owner rows (tomo_common.h:
     tomo_sort_band; mc3_bands_kernel) -- the order inside a plane is local to a row.  Tall, thin stacks either side of the switch:
-    a body whose surface crosses every band boundary, a mask in the first slice (the clamped run is merged with the first plane,
-    now several segments), noise (rows with hundreds of vertices, ties).  Same mesh as the oracle, and -- except for noise, which
-    may tie across buckets -- without the general sort."""
+    a body whose surface crosses every band boundary (`body`: a narrow one, its flat faces fit the hand-written sort's LDS;
+    `wide`: ~40 000 vertices between two planes, the library path), a mask in the first slice (the clamped run is merged with
+    the first plane, now several segments: `first` takes the library path, `first_thin` -- a line of pixels -- the kernel's
+    two-pass (x', then y') order), noise (rows with hundreds of vertices, ties).  Same mesh as the oracle, and -- except for
+    noise, which may tie across buckets -- without the general sort."""
     nz, nx = 5, 48
     rng = np.random.default_rng(ny)
     yy, xx = np.mgrid[0:ny, 0:nx]
     if kind == "noise":
         v = O.smooth(rng.random((nz, ny, nx)) < 0.5, 1, True)
     else:
-        disc = ((yy - ny / 2) / (0.47 * ny)) ** 2 + ((xx - nx / 2) / (0.4 * nx)) ** 2 <= 1.0
+        half = {"body": 0.03, "first_thin": 0.01}.get(kind, 0.4) * nx           # half width of the body along x
+        disc = ((yy - ny / 2) / (0.47 * ny)) ** 2 + ((xx - nx / 2) / half) ** 2 <= 1.0
         v = np.zeros((nz, ny, nx), bool)
-        v[(0 if kind == "first" else 1):4] = disc
+        v[(0 if kind.startswith("first") else 1):4] = disc
         v[2, ::37, 5:nx - 5:3] ^= True                                   # specks: vertices between the planes, in every band
     depths = np.linspace(0.4, 0.8, nz)
     ref = O.SurfaceExtractor().extract_manifold_surface(v, depths, 0.7, 1.1)
     c0 = dict(pipeline.COUNTERS)
+    pipeline._MC3_LARGE.pop((nz + 2, ny + 2, nx + 2, 0), None)
     got = pipeline.extract_surface(to_vol(v, dev), depths, 0.7, 1.1, True, True)
     assert ref is not None and got is not None
     gv, gf = got[0].cpu().numpy(), got[1].cpu().numpy()
     assert gv.shape == ref[0].shape and np.array_equal(gv.view(np.int32), np.ascontiguousarray(ref[0]).view(np.int32))
     assert np.array_equal(gf, ref[1])
     L = _lib.lib()
-    assert L.tomo_mc3_sort_segments(nz + 2, ny + 2) == (nz + 2) * ((1 if ny + 2 <= 1280 else -(-(ny + 2) // 512)) + 1)
+    assert L.tomo_mc3_sort_segments(nz + 2, ny + 2) == (nz + 2) * ((1 if ny + 2 <= 640 else -(-(ny + 2) // 512)) + 1)
     if kind != "noise" and pipeline.MC3:
         assert pipeline.COUNTERS.get("mc3_general_unique", 0) - c0.get("mc3_general_unique", 0) == 0
+    if pipeline.MC3 and pipeline.FUSED_SORT and kind != "noise":
+        # which sort ran: the hand-written kernel, unless a segment (the flat faces of `wide` / `first`) is too long for its LDS
+        # -- then the stage is repeated with the library's segmented sort, once and for good
+        lib = pipeline.COUNTERS.get("mc3_sort_library", 0) - c0.get("mc3_sort_library", 0)
+        assert (lib >= 1) == (kind in ("wide", "first")), (kind, pipeline.COUNTERS)
+        assert bool(pipeline._MC3_LARGE.get((nz + 2, ny + 2, nx + 2, 0))) == (kind in ("wide", "first"))
     # once more from the size hints (everything enqueued before any count is known): identical
     again = pipeline.extract_surface(to_vol(v, dev), depths, 0.7, 1.1, True, True)
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])

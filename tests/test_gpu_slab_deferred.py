@@ -103,8 +103,8 @@ def test_deferred_pass_redone_when_the_surface_outgrows_its_hints(dev):
         pytest.skip("needs the mc3 chain with size hints")
     nz, ny, nx = 120, 112, 128
     small, large = blob(nz, ny, nx, 0.45, 1), blob(nz, ny, nx, 1.0, 2)
-    low = large.copy()
-    low[nz // 2 - 8:] = False
+    low = np.zeros_like(large)                            # a body in the lower slab alone (no flat cut: a cut face of ~8 000 vertices
+    low[:nz // 2 - 8] = blob(nz // 2 - 8, ny, nx, 1.0, 3)   # between two planes would send the sort to its library path: tested below)
     depths = np.full(nz, 0.4)
     volumes = [small, small, large, large, low, low]
     refs = [single_gpu(v, depths, 1.0, 1.0, dev) for v in volumes]
@@ -353,3 +353,36 @@ def test_host_waits_of_a_multi_rank_pass_have_a_deadline():
     assert pend.wait(30.0) == list(range(8))           # with a sane deadline the same download simply arrives
     job = slab.SlabJob(64, 32, 64, type("C", (), {"rank": 0, "world": 2})())
     job._await(dev)                                    # an idle stream: returns at once
+
+
+def test_a_cut_face_too_long_for_the_sort_kernel_takes_the_library_path(dev):
+    """Round 4: the unique stage is one hand-written kernel that keeps a sort segment in LDS (4 096 entries).  A flat cut face --
+    thousands of vertices between the same two planes -- does not fit: the kernel says so (bit 8 of tot[3]), the pass is repeated
+    with the library's segmented sort and the geometry stays on that path.  Single GPU (first pass, then from the size hints) and
+    a 2-rank job whose deferred pass meets the cut: bytes-equal to the oracle's / the single-GPU mesh every time."""
+    if not (pipeline.MC3 and pipeline.FUSED_SORT):
+        pytest.skip("needs the mc3 chain with the fused sort")
+    nz, ny, nx = 120, 112, 128
+    large = blob(nz, ny, nx, 1.0, 2)
+    cut = large.copy()
+    cut[nz // 2 - 8:] = False                              # the lower half of the body: a cut face of ~8 000 vertices
+    depths = np.full(nz, 0.4)
+    pipeline._MC3_LARGE.clear()
+    c0 = dict(pipeline.COUNTERS)
+    ref = single_gpu(cut, depths, 1.0, 1.0, dev)
+    ose = O.SurfaceExtractor()
+    ovp = O.VoxelProcessor()
+    osm = ovp.smooth_voxel_data(ovp.create_voxel_data(list(cut), True, 0, nz, 0), 3, True)
+    ev, ef = ose.extract_manifold_surface(osm, depths, 1.0, 1.0)
+    assert ref[0].tobytes() == ev.tobytes() and np.array_equal(ref[1], ef)
+    assert pipeline.COUNTERS.get("mc3_sort_library", 0) > c0.get("mc3_sort_library", 0) and any(pipeline._MC3_LARGE.values())
+    again = single_gpu(cut, depths, 1.0, 1.0, dev)          # hinted pass: straight to the library path
+    assert again[0].tobytes() == ev.tobytes() and np.array_equal(again[1], ef)
+    small = blob(nz, ny, nx, 0.45, 1)
+    volumes = [small, small, cut, cut, small]
+    refs = [single_gpu(v, depths, 1.0, 1.0, dev) for v in volumes]
+    pipeline._MC3_LARGE.clear()
+    out, stats = run_passes(2, volumes, depths, 1.0, 1.0, dev)
+    for per_rank, r in zip(out, refs):
+        check_pass(per_rank, r)
+    assert all(s[1] >= 1 for s in stats), stats             # the pass that met the cut was redone, on every rank

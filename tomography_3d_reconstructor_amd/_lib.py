@@ -94,6 +94,7 @@ SIGNATURES = {
     "tomo_mc3_sort_workspace_bytes": (_c_i64, [_c_i64, _c_i64]),
     "tomo_mc3_sort_rank": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_mc3_sort_rank_top": (_c_i, [_c_p, _c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_p]),
+    "tomo_mc3_sort_rank_fused": (_c_i, [_c_p, _c_p, _c_i64, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p]),
     "tomo_mc3_faces": (_c_i, [_c_i, _c_i, _c_i, _c_i, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tomo_vertex_finalize": (_c_i, [_c_p, _c_i64, _c_i, _c_p, _c_i64, _c_p, _c_i64, _c_f, _c_f, _c_p]),
     "tomo_mesh_unique_workspace_bytes": (_c_i64, [_c_i64]),

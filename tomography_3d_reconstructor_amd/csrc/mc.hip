@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(256) void mc3_bands_kernel(const McGrid g, const u3
         merge3[0] = ov ? 0u : sliceA[1] + sliceB[0];
         merge3[1] = ov ? 0u : sliceA[1] + sliceB[1];
         merge3[2] = ov ? 0u : sliceA[Nz >= 2 ? 2 : 1] + sliceB[1];
+        merge3[3] = 0u;                                           // the ticket word of uq3_sortrank_kernel (mesh.hip)
         return;
     }
     if (i > nseg) return;
@@ -1138,7 +1139,7 @@ __device__ static inline void mc3_put_vertex(float z, float y, float x, u32 id, 
     vrec[dest] = make_float4(z, y, x, __uint_as_float(id));
     const u32 u = __float_as_uint(between ? z : y);
     keys[dest] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);         // order-preserving float -> uint (fkey32 of mesh.hip)
-    idx[dest] = dest;
+    if (idx) idx[dest] = dest;                                       // (the rocPRIM path sorts pairs; the fused kernel carries positions)
 }
 
 __global__ __launch_bounds__(MC3_BLK) void mc3_vertices_kernel(const McGrid g, const u64 *__restrict__ vox_key, int64_t cap,
@@ -1357,7 +1358,7 @@ TOMO_API int tomo_mc3_vertices(int Nz, int Ny, int Nx, int xorg, const unsigned 
                                float mm_y, float mm_x, float *vrec, uint32_t *keys, uint32_t *idx, void *stream)
 {
     if (Nz < 2 || Ny < 2 || Nx < 2 || !vox_key || !tot || !vox_loc || !vox_flags || !vox_f3 || !vox_c3 || !blk3 || !slice_tab ||
-        !vrec || !keys || !idx || cap <= 0 || (nadj > 0 && (!cum || !adj || ncum != nadj + 1)))
+        !vrec || !keys || cap <= 0 || (nadj > 0 && (!cum || !adj || ncum != nadj + 1)))
         return TOMO_E_ARG;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);

@@ -546,6 +546,321 @@ TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx
                                   __builtin_nanf(""), stream);
 }
 
+// ------------------------------------------------------------------------------------------ mc3: sort + rank in ONE kernel (round 4)
+// The default path of the unique stage since round 4: 100 + 5 + 5 us at 1024^3 against 83 + 5 + 45 for rocPRIM's segmented sort +
+// uq3_merge_kernel + uq3_rank_kernel, which stay as the path for segments too long for LDS (pipeline.FUSED_SORT /
+// TOMO_FUSED_SORT=0: the A/B switch).  One workgroup per sort segment -- a plane band or a between-plane bucket, the segments of
+// mc3_bands_kernel:
+//   1. the segment's 32-bit keys become 64-bit words key << 32 | position (the position breaks ties the way a stable sort
+//      would: vertices arrive in cell scan order); every wave sorts runs of 512 words in registers (8 per lane, a bitonic network:
+//      partners at a distance < 8 are registers of the same lane, the others sit in lane ^ m -- DPP for m = 1, 2, 4, 8, ds_bpermute
+//      for 16 and 32) -- no LDS buffer, no barrier;
+//   2. merge rounds in LDS: a thread finds where its 8 consecutive OUTPUTS begin in the two runs being merged (one binary
+//      search along the merge path) and merges them sequentially; two runs that are already in order (a plane's vertices arrive
+//      grouped by owner row) are copied.  Words are stored with one word of padding per 8 (a thread's window starts 72 B after
+//      its neighbour's: 2-way instead of 16-way bank conflicts);
+//   3. every gather of a thread's rows is issued at once, the rows pass through LDS (the predecessor of a row is its neighbour
+//      there), then final rows, table[id] = position, and the count of places that do not ascend STRICTLY (tot[4]);
+//   4. uq3_seams_kernel checks the seams BETWEEN segments.
+// Measured at 1024^3 (3.5 M vertices in ~2 600 non-empty segments of ~1 200, up to 2 400 near the poles; profiles/
+// r04_sort_experiments.md), launches in us: every element's rank in the sibling run by binary search 171 (LDS pipeline);
+// merge-path rounds from runs of 8: 85 + 73 for a second launch that takes the segments beyond 2 048 -- ~130 of them, nothing
+// overlaps it; runs of 512 sorted in registers first: 74 + 64; a counting sort over the key range with in-bin ranking 80 + 70
+// (the voxelised surface has terraces: hundreds of exactly equal keys in one bin); one WAVE per segment, everything in registers
+// (a bitonic network over up to 64 words per lane): 149 + 113 (200 VGPRs, 64-bit compare-exchanges at VALU rate); this version
+// with 2 560 entries in the first launch (46 KiB: three workgroups per CU, every segment of the bench workloads): 104 + 5, and
+// with the first and the last slices dispatched first: 100 + 5.  All of them are bound by chains of dependent LDS accesses
+// behind barriers.  A ticket + __threadfence per workgroup for a "last one checks the seams" cost 480 us (the fence writes the
+// L2 back, 3 000 times): hence the separate seam kernel.
+// The clamped run of a padded stack -- the between-plane bucket of slice 0 and the plane of slice 1 have the SAME z' when the
+// depth map clamps z < 0 to 0 (uq3_merge_kernel merges them in the rocPRIM path) -- is ONE segment here, ordered by (y', x')
+// through two stable passes (x', then y').  Segments beyond SR_CAP entries (half as many for the clamped run) set bit 8 of
+// tot[3]: the host repeats the stage on the rocPRIM path and remembers it for this geometry (pipeline._MC3_LARGE).
+#define SR_THREADS 256
+#define SR_E 8                       // words per thread and round
+#define SR_CAP 4096
+#define SR_CAP_SMALL 2560             // the variant every segment goes through first (46 KiB of LDS: three workgroups per CU)
+#define SR_PAD(i) ((i) + ((i) >> 3))
+#define SR_WORDS(cap) ((cap) + ((cap) >> 3))
+#define SR_RUN (64 * SR_E)           // words a wave sorts in registers
+
+// the word of lane ^ M: DPP where the pattern is one (quad_perm for 1 and 2, a rotation by 8 inside a row of 16 for 8, the two
+// row shifts by 4 for 4) -- VALU rate, no LDS crossbar; ds_bpermute for 16 and 32 (3 of the 21 cross-lane stages)
+template <int M>
+__device__ static inline u32 sr_lane_xor(u32 x, const int lane)
+{
+    const int v = (int)x;
+    if (M == 1) return (u32)__builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+    if (M == 2) return (u32)__builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+    if (M == 8) return (u32)__builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    if (M == 4) {
+        const int up = __builtin_amdgcn_update_dpp(v, v, 0x104 /* row_shl:4: lane + 4 */, 0xf, 0xf, false);
+        const int dn = __builtin_amdgcn_update_dpp(v, v, 0x114 /* row_shr:4: lane - 4 */, 0xf, 0xf, false);
+        return (u32)((lane & 4) ? dn : up);
+    }
+    return (u32)__shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ static inline u64 sr_shfl_xor(u64 v, const int lane)
+{
+    return ((u64)sr_lane_xor<M>((u32)(v >> 32), lane) << 32) | sr_lane_xor<M>((u32)v, lane);
+}
+
+// Bitonic sorting network over the 512 words of a wave, word e = 8 * lane + r in register v[r]: stage (K, J) compares words at
+// distance J inside blocks of K that alternate between ascending and descending.
+template <int K, int J>
+__device__ static inline void sr_stage(u64 (&v)[SR_E], const int lane)
+{
+    if (J >= SR_E) {
+        constexpr int M = J / SR_E;
+        const bool keep_min = ((((lane * SR_E) & K) == 0) == ((lane & M) == 0));            // (ascending block) == (lower partner)
+#pragma unroll
+        for (int r = 0; r < SR_E; r++) {
+            const u64 o = sr_shfl_xor<(M > 0 ? M : 1)>(v[r], lane);
+            v[r] = (keep_min == (o < v[r])) ? o : v[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < SR_E; r++) {
+            if ((r & J) == 0) {
+                const bool up = K < SR_E ? ((r & K) == 0) : (((lane * SR_E) & K) == 0);
+                const u64 x = v[r], y = v[r | J];
+                const bool sw = (y < x) == up;                                             // out of order for this block's direction
+                v[r] = sw ? y : x;
+                v[r | J] = sw ? x : y;
+            }
+        }
+    }
+}
+template <int K, int J>
+struct SrLevel {
+    __device__ static inline void run(u64 (&v)[SR_E], const int lane)
+    {
+        sr_stage<K, J>(v, lane);
+        SrLevel<K, J / 2>::run(v, lane);
+    }
+};
+template <int K>
+struct SrLevel<K, 0> {
+    __device__ static inline void run(u64 (&)[SR_E], const int) {}
+};
+template <int K>
+struct SrNet {
+    __device__ static inline void run(u64 (&v)[SR_E], const int lane)
+    {
+        SrNet<K / 2>::run(v, lane);
+        SrLevel<K, K / 2>::run(v, lane);
+    }
+};
+template <>
+struct SrNet<1> {
+    __device__ static inline void run(u64 (&)[SR_E], const int) {}
+};
+__device__ static inline void sr_wave_sort(u64 (&v)[SR_E], const int lane) { SrNet<SR_RUN>::run(v, lane); }
+
+// Sorts n distinct words ascending.  make(i) -> word i (called for i < n only); a, b: padded LDS buffers (SR_PAD) with room for
+// n rounded up to a whole run.  Every thread of the workgroup calls it; -> the buffer that holds the result.  Ends with a barrier.
+template <typename Make>
+__device__ static u64 *sr_sort(u64 *a, u64 *b, const int n, Make make)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int base = wave * SR_RUN; base < n; base += (SR_THREADS / 64) * SR_RUN) {          // (uniform per wave: shuffles need every lane)
+        const int g0 = base + lane * SR_E;
+        u64 v[SR_E];
+#pragma unroll
+        for (int k = 0; k < SR_E; k++) v[k] = g0 + k < n ? make(g0 + k) : ~0ull;
+        sr_wave_sort(v, lane);
+#pragma unroll
+        for (int k = 0; k < SR_E; k++) a[SR_PAD(g0) + k] = v[k];              // (the padding past n sorts to the end of the run: never read)
+    }
+    u64 *src = a, *dst = b;
+    for (int L = SR_RUN; L < n; L <<= 1) {
+        __syncthreads();
+        for (int g0 = tid * SR_E; g0 < n; g0 += SR_THREADS * SR_E) {
+            // runs A = [pb, pb + la), B = [pb + L, pb + L + lb); this thread writes outputs g0 .. g0 + 7 of their merge
+            const int pb = g0 & ~(2 * L - 1);
+            const int la = n - pb < L ? n - pb : L;
+            const int lb = n - pb - L < 0 ? 0 : (n - pb - L < L ? n - pb - L : L);
+            const int a0 = pb, b0 = pb + L, d = g0 - pb;
+            u64 out[SR_E];
+            if (lb == 0 || src[SR_PAD(a0 + la - 1)] < src[SR_PAD(b0)]) {
+                // already in order (a plane's vertices arrive grouped by owner row: its runs rarely interleave): a copy
+#pragma unroll
+                for (int k = 0; k < SR_E; k++) out[k] = src[SR_PAD(g0) + k];
+            } else {
+                int lo = d - lb > 0 ? d - lb : 0, hi = d < la ? d : la;
+                while (lo < hi) {                                   // the merge path crosses diagonal d at (lo, d - lo)
+                    const int mid = (lo + hi) >> 1;
+                    if (src[SR_PAD(a0 + mid)] < src[SR_PAD(b0 + d - 1 - mid)]) lo = mid + 1; else hi = mid;
+                }
+                int ia = lo, ib = d - lo;
+                u64 va = ia < la ? src[SR_PAD(a0 + ia)] : ~0ull, vb = ib < lb ? src[SR_PAD(b0 + ib)] : ~0ull;
+#pragma unroll
+                for (int k = 0; k < SR_E; k++) {
+                    const bool ta = va < vb;
+                    out[k] = ta ? va : vb;
+                    ia += ta ? 1 : 0; ib += ta ? 0 : 1;
+                    const int nx = ta ? a0 + ia : b0 + ib;
+                    const bool ok = ta ? ia < la : ib < lb;
+                    const u64 w = ok ? src[SR_PAD(nx)] : ~0ull;
+                    va = ta ? w : va; vb = ta ? vb : w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SR_E; k++) dst[SR_PAD(g0) + k] = out[k];       // (past n: ~0 or stale, never read)
+        }
+        u64 *t = src; src = dst; dst = t;
+    }
+    __syncthreads();
+    return src;
+}
+
+// CAP entries of LDS per workgroup (18 B each: the two padded sort buffers, later the gathered rows).  The chain launches the
+// SR_CAP_SMALL variant for every segment and the SR_CAP variant behind it for the segments the first one left (it skips the
+// others at once: 5 us when there are none).
+template <int CAP>
+__global__ __launch_bounds__(SR_THREADS) void uq3_sortrank_kernel(const float4 *__restrict__ vrec, const u32 *__restrict__ keys,
+                                                                  const u32 *__restrict__ offsets, const int NB, const int Nz,
+                                                                  float *__restrict__ uniq, int32_t *__restrict__ table,
+                                                                  u64 *__restrict__ tot, const float z_top)
+{
+    constexpr int EP = CAP / SR_THREADS;
+    extern __shared__ __attribute__((aligned(16))) u64 s_buf[];   // 2 * SR_WORDS(CAP) words
+    u64 *const s_a = s_buf, *const s_b = s_buf + SR_WORDS(CAP);
+    float4 *const s_rows = (float4 *)s_buf;                       // (after the sort: the rows in final order)
+    u32 *const s_red = (u32 *)s_b;                                // (used before the buffers are filled)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroups are dispatched in index order: the segments of the first and the last slices go first, alternately (the long
+    // between-plane buckets of a closed body sit at its poles; started last they would finish alone)
+    const int seg = (blockIdx.x & 1) ? (int)gridDim.x - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1);
+    u32 o0 = offsets[seg];
+    int n = (int)(offsets[seg + 1] - o0);
+    const u64 nv = tot[1];
+    // ---- the clamped run: bucket of slice 0 (segment NB) + plane of slice 1 (segments NB + 1 .. 2 NB)
+    bool uni = false;
+    if (Nz >= 2 && seg >= NB && seg <= 2 * NB) {
+        const u32 o1 = offsets[NB], o2 = offsets[NB + 1], o3 = offsets[2 * NB + 1];
+        if (o2 > o1 && o3 > o2) {
+            u32 kmax = 0;
+            for (u32 i = o1 + tid; i < o2; i += SR_THREADS) kmax = max(kmax, keys[i]);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) kmax = max(kmax, (u32)__shfl_xor((int)kmax, d, 64));
+            if (lane == 0) s_red[wave] = kmax;
+            __syncthreads();
+            kmax = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+            if (kmax >= fkey32(vrec[o2].x)) {                     // a row of the bucket does not sort in front of the plane: one run
+                if (seg == NB) { uni = true; o0 = o1; n = (int)(o3 - o1); }
+                else n = 0;                                       // a band of the plane: the bucket's workgroup takes it
+            }
+            __syncthreads();
+        }
+    }
+    // which variant takes this segment (the clamped run keeps its first order in one buffer: half the capacity)
+    constexpr int UCAP = CAP / 2 / SR_RUN * SR_RUN, UCAP_SMALL = SR_CAP_SMALL / 2 / SR_RUN * SR_RUN;   // whole runs per half buffer
+    const int mine = uni ? UCAP : CAP, below = CAP > SR_CAP_SMALL ? (uni ? UCAP_SMALL : SR_CAP_SMALL) : 0;
+    if (n > mine) {
+        if (CAP >= SR_CAP && tid == 0) atomicOr((unsigned long long *)&tot[3], 8ull);   // too long for LDS: the host takes the rocPRIM path
+        n = 0;
+    }
+    if (n <= below) n = 0;                                        // the smaller variant has done it
+    if (n == 0) return;
+    const u64 *sorted;
+    const u32 *first = nullptr;                                   // (clamped run) position after the first pass
+    if (!uni) {
+        sorted = sr_sort(s_a, s_b, n, [=](int i) { return ((u64)keys[o0 + i] << 32) | (u32)i; });
+    } else {
+        // stable by x', then stable by y': the (y', x') order of rows that share their z'.  Both passes in the two halves of
+        // s_a (n <= UCAP), the first order kept in s_b
+        u64 *const h0 = s_a, *const h1 = s_a + SR_WORDS(UCAP);
+        const u64 *p1 = sr_sort(h0, h1, n, [=](int i) { return ((u64)fkey32(vrec[o0 + i].z) << 32) | (u32)i; });
+        u32 *ord = (u32 *)s_b;
+        for (int i = tid; i < n; i += SR_THREADS) ord[i] = (u32)p1[SR_PAD(i)];
+        __syncthreads();
+        sorted = sr_sort(h0, h1, n, [=](int i) { return ((u64)fkey32(vrec[o0 + ord[i]].y) << 32) | (u32)i; });
+        first = ord;
+    }
+    // ---- the rows in order: every gather of a thread is in flight at once, the rows pass through LDS (the predecessor of a
+    //      row is its neighbour there), then rows, table and the strict-ascending check inside the segment
+    u32 p[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {                                // (no store under a condition: the arrays stay in registers)
+        const int i = tid + SR_THREADS * e, ii = i < n ? i : n - 1;
+        const u32 q = (u32)sorted[SR_PAD(ii)];
+        p[e] = first ? first[q] : q;
+    }
+    __syncthreads();
+    float4 r[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) r[e] = vrec[o0 + p[e]];
+#pragma unroll
+    for (int e = 0; e < EP; e++)                                  // every gather is issued before the first one is waited for (the
+        asm volatile("" : "+v"(r[e].x), "+v"(r[e].y), "+v"(r[e].z), "+v"(r[e].w));   // compiler sinks each load to its store otherwise)
+#pragma unroll
+    for (int e = 0; e < EP; e++) if (tid + SR_THREADS * e < n) s_rows[tid + SR_THREADS * e] = r[e];
+    __syncthreads();
+    u32 nviol = 0, ntop = 0;
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        const int i = tid + SR_THREADS * e;
+        if (i < n && (u64)(o0 + i) < nv) {
+            const float4 a = s_rows[i];
+            if (i > 0 && !rec_less(s_rows[i - 1], a)) nviol++;
+            typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+            *(f3u *)(uniq + 3 * (int64_t)(o0 + i)) = (f3u){a.x, a.y, a.z};
+            table[__float_as_uint(a.w)] = (int32_t)(o0 + i);
+            if (a.x == z_top) ntop++;
+        }
+    }
+    nviol = wave_sum(nviol); ntop = wave_sum(ntop);
+    if (lane == 0 && nviol) atomicAdd((unsigned long long *)&tot[4], (unsigned long long)nviol);
+    if (lane == 0 && ntop) atomicAdd((unsigned long long *)&tot[7], (unsigned long long)ntop);
+}
+
+// the seams between the segments: row offsets[s] - 1 must sort in front of row offsets[s] (one thread per segment)
+__global__ __launch_bounds__(256) void uq3_seams_kernel(const float *__restrict__ uniq, const u32 *__restrict__ offsets, const int nseg,
+                                                        u64 *__restrict__ tot)
+{
+    const int s = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (s < nseg && tot[3] == 0) {
+        const u32 q0 = offsets[s];
+        if (q0 != 0 && (u64)q0 < tot[1] && offsets[s + 1] != q0) {            // nothing in front / an empty segment: its successor checks
+            const float *r = uniq + 3 * (int64_t)(q0 - 1);
+            bad = !(r[0] < r[3] || (r[0] == r[3] && (r[1] < r[4] || (r[1] == r[4] && r[2] < r[5]))));
+        }
+    }
+    const u64 nbad = (u64)__popcll(__ballot(bad));
+    if ((threadIdx.x & 63) == 0 && nbad) atomicAdd((unsigned long long *)&tot[4], (unsigned long long)nbad);
+}
+
+// keys: the 32-bit sort keys mc3_vertices wrote (its idx array is not needed: the sort carries positions); slice_tab: as for
+// tomo_mc3_sort_rank_top.  No workspace.  Segments too long for the kernel's LDS are reported in tot[3] (bit 8).
+TOMO_API int tomo_mc3_sort_rank_fused(const float *vrec, const uint32_t *keys, int64_t cap_v, int Nz, int Ny, uint32_t *slice_tab,
+                                      unsigned long long *tot, float *uniq, int32_t *table, float z_top, void *stream)
+{
+    if (!vrec || !keys || !slice_tab || !tot || !uniq || !table || cap_v <= 0 || Nz < 1 || Ny < 1) return TOMO_E_ARG;
+    if (cap_v >= 0x7fffffffll || Nz > UQ_MAX_SLABS) return TOMO_E_SIZE;
+    const int NB = TOMO_SORT_NB(Ny);
+    const int64_t nseg = (int64_t)(NB + 1) * Nz;
+    if (nseg >= 0x7fffffffll) return TOMO_E_SIZE;
+    const u32 *offsets = slice_tab + 2 * ((int64_t)Nz + 1);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    const size_t lds_small = 2 * SR_WORDS(SR_CAP_SMALL) * sizeof(u64), lds_big = 2 * SR_WORDS(SR_CAP) * sizeof(u64);
+    if (!attr_set) {                                                   // 72 KiB of dynamic LDS needs the opt-in (idempotent; a race only repeats it)
+        if (hipFuncSetAttribute((const void *)uq3_sortrank_kernel<SR_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) != hipSuccess)
+            return TOMO_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((uq3_sortrank_kernel<SR_CAP_SMALL>), dim3((unsigned)nseg), dim3(SR_THREADS), lds_small, s, (const float4 *)vrec,
+                       (const u32 *)keys, offsets, NB, Nz, uniq, table, (u64 *)tot, z_top);
+    hipLaunchKernelGGL((uq3_sortrank_kernel<SR_CAP>), dim3((unsigned)nseg), dim3(SR_THREADS), lds_big, s, (const float4 *)vrec,
+                       (const u32 *)keys, offsets, NB, Nz, uniq, table, (u64 *)tot, z_top);
+    hipLaunchKernelGGL(uq3_seams_kernel, dim3((unsigned)ceil_div64(nseg, 256)), dim3(256), 0, s, (const float *)uniq, offsets, (int)nseg,
+                       (u64 *)tot);
+    return tomo_status();
+}
+
 // ------------------------------------------------------------------------------------------ lookup
 // Index of every query row in a lexicographically sorted, duplicate-free (U,3) row list (binary search); a row that is
 // not there gets -1 and is counted in *missing.  The Z-slab job uses it to number the few thousand shared-plane vertices

@@ -15,11 +15,13 @@
 
 // Sort segments of the mc3 chain (mc.hip writes their offsets, mesh.hip sorts inside them): per slice Z the in-plane
 // vertices cut into bands of tomo_sort_band(Ny) owner rows, then the between-plane vertices -- TOMO_SORT_NB(Ny) + 1 segments.
-// The segmented sort runs one workgroup per segment and keeps up to 4 096 entries in LDS: its time grows with the NUMBER of
-// segments (measured: 32-row bands, 34 K segments at 1024^3: 166 us against 85 us for whole planes) and explodes beyond 4 096
-// entries per segment (2048^2 slices, ~6 700 per plane: 922 us for 3.7 M vertices).  So: whole planes up to 1280 rows,
-// bands of 512 rows above.
-__host__ __device__ static inline int tomo_sort_band(int Ny) { return Ny <= 1280 ? (Ny > 0 ? Ny : 1) : 512; }
+// The order inside a plane is local to an owner ROW, so any band height is correct.  Round 4: the hand-written sort (mesh.hip,
+// uq3_sortrank_kernel) keeps a segment in LDS -- 2 048 entries in its small variant -- and does not mind many segments: bands of
+// 512 rows from 640 rows on (a 1024^2 plane of the bench ellipsoid holds ~2 300 vertices, a 2048^2 one ~3 900).  (Rounds 2-3,
+// rocPRIM's segmented sort, one workgroup per segment: whole planes up to 1280 rows -- its time grows with the NUMBER of
+// segments, 32-row bands at 1024^3: 166 us against 85 -- and bands of 512 above: beyond 4 096 entries per segment it falls
+// off a cliff, 922 us for 3.7 M vertices at 2048^2.  It is still the path for segments too long for LDS.)
+__host__ __device__ static inline int tomo_sort_band(int Ny) { return Ny <= 640 ? (Ny > 0 ? Ny : 1) : 512; }
 #define TOMO_SORT_NB(Ny) (((Ny) + tomo_sort_band(Ny) - 1) / tomo_sort_band(Ny))
 
 typedef unsigned long long u64;

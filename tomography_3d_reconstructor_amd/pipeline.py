@@ -638,6 +638,11 @@ def extract_surface_submit(vol: BitVolume, slice_depths, mm_per_pixel_y, mm_per_
 # ----------------------------------------------------------------------------- mc3: marching cubes + finalise + unique, one chain
 MC3 = os.environ.get("TOMO_MC_PATH", "mc3") != "old"     # manifold=True surfaces through the mc3 chain (csrc/mc.hip, "mc3")
 _MC3_HINT = {}          # field geometry -> (active voxels, vertices, triangles) of the last surface of that geometry
+# The unique stage: ONE hand-written kernel (tomo_mc3_sort_rank_fused; a workgroup per sort segment, everything in LDS) unless
+# the last surface of the geometry had a segment too long for it (a flat cap of > 4 096 vertices between two planes, a noise
+# slice): then rocPRIM's segmented sort + merge + rank kernels (tomo_mc3_sort_rank_top), as in rounds 2-3.
+FUSED_SORT = os.environ.get("TOMO_FUSED_SORT", "1") not in ("", "0")     # A/B switch
+_MC3_LARGE = {}         # field geometry -> True: use the rocPRIM path
 _PINNED_TOT = {}
 
 
@@ -838,15 +843,22 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
     def vertices_sort(cap, cap_v):
         m._vrec = torch.empty((cap_v, 4), dtype=torch.float32, device=dev)
         keys = torch.empty(cap_v, dtype=torch.int32, device=dev)
-        idx = torch.empty(cap_v, dtype=torch.int32, device=dev)
         m._uniq = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
         m.table = torch.empty(4 * cap, dtype=torch.int32, device=dev)
-        wsb = L.tomo_mc3_sort_workspace_bytes(cap_v, L.tomo_mc3_sort_segments(f.Nz, f.Ny))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        fused = FUSED_SORT and not _MC3_LARGE.get(hint_key)
+        idx = None if fused else torch.empty(cap_v, dtype=torch.int32, device=dev)
         _lib.check(L.tomo_mc3_vertices(f.Nz, f.Ny, f.Nx, f.xorg, _p(m._vox_key), cap, _p(tot), _p(m._vox_loc), _p(m._vox_flags),
                                        _p(m._vox_f3), _p(m._vox_c3), _p(m._blk3), _p(m._slice_tab), int(z_offset), 1, _p(cum_t), ncum,
                                        _p(adj_t), nadj, mmy, mmx, _p(m._vrec), _p(keys), _p(idx), st), "tomo_mc3_vertices")
         m._cap_v = cap_v
+        if fused:
+            COUNTERS["mc3_sort_fused"] = COUNTERS.get("mc3_sort_fused", 0) + 1
+            _lib.check(L.tomo_mc3_sort_rank_fused(_p(m._vrec), _p(keys), cap_v, f.Nz, f.Ny, _p(m._slice_tab), _p(tot), _p(m._uniq),
+                                                  _p(m.table), z_top, st), "tomo_mc3_sort_rank_fused")
+            return
+        COUNTERS["mc3_sort_library"] = COUNTERS.get("mc3_sort_library", 0) + 1
+        wsb = L.tomo_mc3_sort_workspace_bytes(cap_v, L.tomo_mc3_sort_segments(f.Nz, f.Ny))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _lib.check(L.tomo_mc3_sort_rank_top(_p(m._vrec), _p(keys), _p(idx), cap_v, f.Nz, f.Ny, _p(m._slice_tab), _p(tot), _p(m._uniq),
                                             _p(m.table), _p(ws), wsb, z_top, st), "tomo_mc3_sort_rank_top")
 
@@ -855,6 +867,8 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
         if host is not None:
             if host[3]:
                 COUNTERS["mc3_hint_miss"] = COUNTERS.get("mc3_hint_miss", 0) + 1
+                if host[3] & 8:
+                    _MC3_LARGE[hint_key] = True                  # a sort segment too long for the fused kernel: the library path from now on
                 host = faces = None                              # something did not fit: redo with exact sizes
             else:
                 COUNTERS["mc3_hint_hit"] = COUNTERS.get("mc3_hint_hit", 0) + 1
@@ -876,6 +890,15 @@ def mc3_vertices(f: Field, slice_depths, mm_per_pixel_y, mm_per_pixel_x, add_pad
                 raise _lib.TomoError("mesh too large for 32-bit indices")
             vertices_sort(na, nv)
             m._cap_f = max(nf, 1)
+            if FUSED_SORT and not _MC3_LARGE.get(hint_key):
+                # the fused kernel reports a segment it cannot hold in LDS (bit 8 of tot[3]): the stage is repeated on the library
+                # path, and stays there for this geometry
+                host = _download_tot(tot)
+                if host[3] & 8:
+                    _MC3_LARGE[hint_key] = True
+                    tot[3:5].zero_()
+                    tot[7].zero_()
+                    vertices_sort(na, nv)
             if with_faces:
                 faces = m.faces()
             host = _download_tot(tot)
