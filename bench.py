@@ -80,6 +80,9 @@ def parse(argv=None):
     ap.add_argument("--sparse-field", action="store_true",
                     help="opt-in: do not materialise the parts of the float field that marching cubes cannot read "
                          "(same mesh; NOT the headline configuration -- the roofline entry then only carries a note)")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="A/B: every kernel of a pass on ONE stream (rounds 1-3); default: the front of a pass (pack + close + smoothing) on "
+                         "a second stream, so that it runs under the marching-cubes chain of the pass before")
     ap.add_argument("--read-every-pass", action="store_true",
                     help="A/B: the host reads the counters of a pass before it enqueues the next one (the GPU idles meanwhile)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="edge of the cube the CPU oracle is timed on (default: the workload itself)")
@@ -271,12 +274,43 @@ def one_pass(mask, depths):
     return pipeline.extract_surface(vol, depths, 1.0, 1.0, True, True)
 
 
-def one_pass_submit(mask, depths):
-    """one_pass whose counters have not been read yet: -> an object with .result() (pipeline.extract_surface_submit)."""
+_FRONT = {}          # device -> the second HIP stream of one_pass_submit
+
+
+def one_pass_submit(mask, depths, overlap_front=True):
+    """one_pass whose counters have not been read yet: -> an object with .result() (pipeline.extract_surface_submit).
+    overlap_front: the front of the pass -- pack + close ends + smoothing, which depends on the mask alone and streams at HBM
+    rate -- is enqueued on a SECOND HIP stream; the field kernel and the marching-cubes chain wait for it (an event) on the main
+    stream.  A caller that submits pass k + 1 before it collects pass k (bench.py's timed loop) thereby lets the front of pass
+    k + 1 run under the latency-bound marching-cubes chain of pass k.  Every pass is still complete and checked when its
+    .result() returns."""
+    import torch
     from tomography_3d_reconstructor_amd import pipeline
-    vol = pipeline.pack_closed(mask)
-    vol = pipeline.smooth(vol, 3, True)
-    return pipeline.extract_surface_submit(vol, depths, 1.0, 1.0, True, True)
+    if not overlap_front:
+        vol = pipeline.pack_closed(mask)
+        vol = pipeline.smooth(vol, 3, True)
+        return pipeline.extract_surface_submit(vol, depths, 1.0, 1.0, True, True)
+    main = torch.cuda.current_stream(mask.device)
+    front = _FRONT.get((str(mask.device), main.cuda_stream))
+    if front is None:
+        front = _FRONT[(str(mask.device), main.cuda_stream)] = torch.cuda.Stream(device=mask.device)
+        front.wait_stream(main)                          # whatever produced the mask is done before the first front runs
+    gate = _FRONT.get(("gate", str(mask.device), main.cuda_stream))
+    with torch.cuda.stream(front):
+        if gate is not None:
+            front.wait_event(gate)                        # not next to the field kernel of the pass before (both stream at HBM rate): behind it
+        vol = pipeline.smooth(pipeline.pack_closed(mask), 3, True)
+        done = torch.cuda.Event()
+        done.record(front)
+    main.wait_event(done)
+    vol.bits.record_stream(main)                         # allocated on the front stream, read by the main one: the allocator must know
+    if not (pipeline.MC3 and not pipeline.FIELD_SPARSE):
+        return pipeline.extract_surface_submit(vol, depths, 1.0, 1.0, True, True)
+    f = pipeline.make_field(vol, True, True)
+    gate = torch.cuda.Event()
+    gate.record(main)
+    _FRONT[("gate", str(mask.device), main.cuda_stream)] = gate
+    return pipeline.PendingSurface(surface=pipeline.mc3_vertices(f, depths, 1.0, 1.0, True, defer=True))
 
 
 def _cpu_chunk(job):
@@ -609,11 +643,11 @@ def run(args, world, cpu=None):
         d = np.full(z, 1.0)
         r = None
         for _ in range(2):
-            r = one_pass_submit(m, d).result()
+            r = one_pass_submit(m, d, not args.one_stream).result()
             beat[0] = time.monotonic()
         pend = None
         for _ in range(warmup):
-            nxt = one_pass_submit(m, d)
+            nxt = one_pass_submit(m, d, not args.one_stream)
             if pend is not None:
                 r = pend.result()
             pend = nxt
@@ -623,7 +657,7 @@ def run(args, world, cpu=None):
         t0 = time.perf_counter()
         pend = None
         for _ in range(steps):
-            nxt = one_pass_submit(m, d)
+            nxt = one_pass_submit(m, d, not args.one_stream)
             if pend is not None:
                 r = pend.result()
             pend = nxt
@@ -659,7 +693,7 @@ def run(args, world, cpu=None):
             depths = np.full(z, 1.0)
 
             def submit():
-                return one_pass_submit(mask, depths)
+                return one_pass_submit(mask, depths, not args.one_stream)
 
             def collect(p):
                 return p.result()
@@ -832,13 +866,20 @@ def run(args, world, cpu=None):
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "value_note": ("the host reads every pass before it enqueues the next" if args.read_every_pass else
-                       "PIPELINED submission: passes run strictly one after the other on one stream, but the host enqueues pass k+1 before "
-                       "it reads the counters of pass k (rounds 1-2 read every pass: `read_every_pass_ms_per_step`)"),
+                       "PIPELINED submission: the host enqueues pass k+1 before it reads the counters of pass k (rounds 1-2 read every "
+                       "pass: `read_every_pass_ms_per_step`)" + ("" if (args.one_stream or dist) else
+                       "; and the FRONT of pass k+1 (pack + close ends + smoothing: needs the mask alone) is enqueued on a second HIP "
+                       "stream, so it runs under the marching-cubes chain of pass k -- field kernel and chain of consecutive passes "
+                       "still run strictly in order on the main stream (`one_stream_ms_per_step`: everything on one stream, round 3's "
+                       "`ms_per_step`)")),
         "config": {"workload": workload, "workload_id": wname, "parallelism": parallelism,
                    "inputs": "uint8 mask stack resident in HBM", "outputs": "final (vertices, faces) resident in HBM",
                    "field": "tile-sparse (opt-in)" if pipeline.FIELD_SPARSE else "dense",
                    "submission": ("host reads every pass before enqueueing the next" if args.read_every_pass else
-                                  "passes strictly one after the other on one stream; the host enqueues pass k+1 before it reads the counters of pass k"),
+                                  ("passes strictly one after the other on one stream; the host enqueues pass k+1 before it reads the counters of pass k"
+                                   if (args.one_stream or dist) else
+                                   "the host enqueues pass k+1 before it reads the counters of pass k; pack + close + smoothing of a pass on a second "
+                                   "stream (may run under the marching-cubes chain of the pass before), field + chain in order on the main stream")),
                    "n_vertices": nverts, "n_faces": nfaces},
         "parity_in_run": parity["parity_in_run"], "parity": parity,
         "roofline": roofline,
@@ -869,6 +910,20 @@ def run(args, world, cpu=None):
         out["read_every_pass_ms_per_step"] = round((time.perf_counter() - t0) / max(4, min(args.steps, 10)) * 1e3, 3)
         out["read_every_pass_note"] = "side measurement: the host reads a pass's counters before it enqueues the next pass (round 1 / 2's `ms_per_step`)"
         del r
+        if not args.one_stream:
+            kk = max(4, min(args.steps, 10))
+            pend = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kk):
+                nxt = one_pass_submit(mask, depths, False)
+                if pend is not None:
+                    pend.result()
+                pend = nxt
+            pend.result()
+            torch.cuda.synchronize()
+            out["one_stream_ms_per_step"] = round((time.perf_counter() - t0) / kk * 1e3, 3)
+            out["one_stream_note"] = "side measurement: every kernel of a pass on ONE stream, pass after pass (round 3's `ms_per_step`)"
         tif = two_in_flight(mask, depths, max(4, min(args.steps, 10)))
         if tif is not None:
             out["two_in_flight_ms_per_pass"] = round(tif, 3)

@@ -298,6 +298,114 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
                     lo_fixed, hi_fixed, below, above, zr);
 }
 
+// ---- the same pass with the boundary words of a run HANDED OVER inside the workgroup (round 4): the four waves of a workgroup
+// take four CONSECUTIVE runs of one (row, 1024-voxel group) column; a wave loads only its own slices, writes the outputs whose
+// three taps it holds as it marches, and at the end the first and the last word of every run pass through LDS: the first / last
+// output of a run is written after one barrier.  Only the two outer waves of a workgroup read a neighbour's slice, so the mask
+// is read (4 zr + 2) / (4 zr) times instead of (zr + 2) / zr (1.016 against 1.0625 at zr = 32).  Outputs za .. zb - 1, zb - za a
+// multiple of PC_U, split into `nwg` workgroups per column and four runs each, a whole number of groups of PC_U slices per run
+// (the first `extra` runs one group longer).  End slices as in pack_close_body.
+__global__ __launch_bounds__(256) void pack_close_ho_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
+                                                            int nx, int wx, int groups, int nwg, int za, int zb, int lo_fixed,
+                                                            int hi_fixed, const u64 *__restrict__ below,
+                                                            const u64 *__restrict__ above)
+{
+    __shared__ u64 s_edge[4][2][16];                               // [wave][first / last word of its run][word of the group]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t cols = (int64_t)ny * groups;
+    const int c = (int)(blockIdx.x / cols);                        // consecutive workgroups: consecutive columns of one z range
+    const int64_t rem = blockIdx.x - (int64_t)c * cols;
+    const int y = (int)(rem / groups), g = (int)(rem - (int64_t)y * groups);
+    const int x = g * 1024 + lane * 16, word = g * 16 + (lane >> 2);
+    const bool inx = x < nx, inw = word < wx;
+    const int G = (zb - za) / PC_U, nruns = 4 * nwg, base = G / nruns, extra = G - base * nruns;
+    const int q = 4 * c + w;
+    const int z0 = za + PC_U * (q * base + (q < extra ? q : extra)), groups_z = base + (q < extra ? 1 : 0), z1 = z0 + PC_U * groups_z;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int64_t slice_bytes = (int64_t)ny * nx, slice_words = (int64_t)ny * wx;
+    const uint8_t *p = mask + (int64_t)y * nx + (inx ? x : 0) + (int64_t)z0 * slice_bytes;
+    auto word_fast = [&](u4 t) -> u64 {
+        const u32 piece = nonzero_nibble(t.x) | (nonzero_nibble(t.y) << 4) | (nonzero_nibble(t.z) << 8) | (nonzero_nibble(t.w) << 12);
+        u64 v = (u64)(inx ? piece : 0u) << (16 * (lane & 3));
+        v |= __shfl_xor(v, 1, 64);
+        v |= __shfl_xor(v, 2, 64);
+        return v;
+    };
+    // the slice beyond the workgroup's range, for its first and its last wave only: another slice of the mask, a filled end slice
+    // (bits), a neighbour rank's slice (below / above) or nothing
+    u64 outer = 0ull;
+    u4 t_outer = {0u, 0u, 0u, 0u};
+    bool outer_raw = false;
+    if (w == 0 || w == 3) {
+        const int zo = w == 0 ? z0 - 1 : z1;
+        if (zo < 0) outer = (below && inw) ? below[(int64_t)y * wx + word] : 0ull;
+        else if (zo >= nz) outer = (above && inw) ? above[(int64_t)y * wx + word] : 0ull;
+        else if ((zo == 0 && lo_fixed) || (zo == nz - 1 && hi_fixed)) outer = inw ? bits[(int64_t)zo * slice_words + (int64_t)y * wx + word] : 0ull;
+        else { t_outer = __builtin_nontemporal_load((const u4 *)(mask + (int64_t)y * nx + (inx ? x : 0) + (int64_t)zo * slice_bytes)); outer_raw = true; }
+    }
+    u4 t[PC_U];
+#pragma unroll
+    for (int j = 0; j < PC_U; j++) t[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
+    p += (int64_t)PC_U * slice_bytes;
+    u64 *qo = bits + (int64_t)y * wx + word + (int64_t)z0 * slice_words;
+    const bool st = (lane & 3) == 0 && inw;
+    // first group: words 0 .. 3; outputs 1, 2 (output 0 waits for the hand-over, output 3 for word 4)
+    u64 w0, w1, prev, cur;
+    {
+        u4 n[PC_U];
+        const bool more = groups_z > 1;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) n[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
+            p += (int64_t)PC_U * slice_bytes;
+        }
+        w0 = word_fast(t[0]); w1 = word_fast(t[1]);
+        prev = w0; cur = w1;
+#pragma unroll
+        for (int j = 2; j < PC_U; j++) {
+            const u64 next = word_fast(t[j]);
+            if (st) qo[(int64_t)(j - 1) * slice_words] = cur | (prev & next);
+            prev = cur; cur = next;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) t[j] = n[j];
+        }
+    }
+    // groups 1 .. groups_z - 1: word k arrives -> output k - 1
+    u64 *qq = qo + (int64_t)(PC_U - 1) * slice_words;              // next output to write: index PC_U - 1
+    for (int gz = 1; gz < groups_z; gz++) {
+        u4 n[PC_U];
+        const bool more = gz + 1 < groups_z;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) n[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
+            p += (int64_t)PC_U * slice_bytes;
+        }
+#pragma unroll
+        for (int j = 0; j < PC_U; j++) {
+            const u64 next = word_fast(t[j]);
+            if (st) qq[(int64_t)j * slice_words] = cur | (prev & next);
+            prev = cur; cur = next;
+        }
+        qq += (int64_t)PC_U * slice_words;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < PC_U; j++) t[j] = n[j];
+        }
+    }
+    // prev, cur = the last two words of the run; qq points at the last output
+    if (outer_raw) outer = word_fast(t_outer);
+    if ((lane & 3) == 0) { s_edge[w][0][lane >> 2] = w0; s_edge[w][1][lane >> 2] = cur; }
+    __syncthreads();
+    const u64 before = w == 0 ? outer : s_edge[w - 1][1][lane >> 2];
+    const u64 after = w == 3 ? outer : s_edge[w + 1][0][lane >> 2];
+    if (st) {
+        qo[0] = w0 | (before & w1);
+        qq[0] = cur | (prev & after);
+    }
+}
+
 // unpack: one thread per 8 voxels (one byte of the word) -> 8 output bytes.
 __global__ __launch_bounds__(256) void unpack_kernel(const u64 *__restrict__ bits, uint8_t *__restrict__ mask,
                                                      int64_t rows, int nx, int wx)
@@ -797,6 +905,38 @@ TOMO_API int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64
     return fill_holes_launch(first, last, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream);
 }
 
+// Outputs za .. zb - 1 of the fused pack + stencil pass: long ranges through pack_close_ho_kernel (its first (zb - za) % PC_U
+// slices through the generic kernel, a launch of a few us), short ones through pack_close_kernel in runs of zr slices.
+static int pack_close_launch(const uint8_t *mask, u64 *bits, int nz, int ny, int nx, int wx, int groups, int za, int zb, int lo_fixed,
+                             int hi_fixed, const u64 *below, const u64 *above, hipStream_t st)
+{
+    static const bool handover = !(getenv("TOMO_PACK_HANDOVER") && atoi(getenv("TOMO_PACK_HANDOVER")) == 0);
+    const int G = (zb - za) / PC_U;
+    const int nwg = (G + 4 * (PC_ZR / PC_U) - 1) / (4 * (PC_ZR / PC_U));         // ~PC_ZR slices per wave
+    if (handover && zb - za >= 4 * PC_ZR && G >= 4 * nwg) {
+        const int head = (zb - za) % PC_U;
+        if (head) {
+            const int64_t blocks0 = ceil_div64((int64_t)ny * groups, 4);
+            if (blocks0 > 0x7fffffff) return TOMO_E_SIZE;
+            hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks0), dim3(256), 0, st, mask, bits, nz, ny, nx, wx, groups, 1, za,
+                               za + head, lo_fixed, hi_fixed, below, above, PC_ZR);
+        }
+        const int64_t blocks = (int64_t)ny * groups * nwg;
+        if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+        hipLaunchKernelGGL(pack_close_ho_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mask, bits, nz, ny, nx, wx, groups, nwg,
+                           za + head, zb, lo_fixed, hi_fixed, below, above);
+        return tomo_status();
+    }
+    // a short range (the slices at an end of a slab) in runs of 8: four times the waves, a quarter of the serial march each
+    const int zr = (zb - za) <= 2 * PC_ZR ? PC_ZR / 4 : PC_ZR;
+    const int runs = (zb - za + zr - 1) / zr;
+    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
+    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mask, bits, nz, ny, nx, wx, groups, runs, za, zb,
+                       lo_fixed, hi_fixed, below, above, zr);
+    return tomo_status();
+}
+
 // np.stack + _close_volume_ends (voxel_processor.py:46, :56-77) from the uint8 mask stack to the closed bit volume:
 // pack the two end slices, fill their holes, then the fused pack + stencil pass.  scratch: ny * wx + 8 words (the fill's).
 // Requires what pack16_kernel requires (nx % 16 == 0, 16-byte aligned mask) and nz >= 3; returns TOMO_E_ARG otherwise
@@ -814,12 +954,7 @@ TOMO_API int tomo_pack_close_ends(const uint8_t *mask, uint64_t *bits, int nz, i
     int rc = fill_holes_launch((u64 *)bits, (u64 *)bits + (int64_t)(nz - 1) * ny * wx, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream,
                                true);
     if (rc) return rc;
-    const int runs = (nz - 2 + PC_ZR - 1) / PC_ZR;
-    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
-    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs, 1, nz - 1, 1, 1, (const u64 *)nullptr, (const u64 *)nullptr, PC_ZR);
-    return tomo_status();
+    return pack_close_launch(mask, (u64 *)bits, nz, ny, nx, wx, groups, 1, nz - 1, 1, 1, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // tomo_pack_close_slab for the output slices [z_from, z_to) only: the slices in the middle of a slab depend on nothing but
@@ -837,14 +972,8 @@ TOMO_API int tomo_pack_close_range(const uint8_t *mask, uint64_t *bits, int nz, 
     if ((za == 0 && !below) || (zb == nz && !above)) return TOMO_E_ARG;
     const int wx = (int)tomo_words_per_row(nx);
     const int groups = (wx + 15) / 16;
-    // a short range (the 32 slices at an end of a slab) in runs of 8: four times the waves, a quarter of the serial march each
-    const int zr = (zb - za) <= 2 * PC_ZR ? PC_ZR / 4 : PC_ZR;
-    const int runs = (zb - za + zr - 1) / zr;
-    const int64_t waves = (int64_t)ny * groups * runs, blocks = ceil_div64(waves, 4);
-    if (blocks > 0x7fffffff) return TOMO_E_SIZE;
-    hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, (u64 *)bits, nz, ny, nx, wx,
-                       groups, runs, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above, zr);
-    return tomo_status();
+    return pack_close_launch(mask, (u64 *)bits, nz, ny, nx, wx, groups, za, zb, lo_fixed, hi_fixed, (const u64 *)below, (const u64 *)above,
+                             (hipStream_t)stream);
 }
 
 // The stencil alone, on n bit-packed slices with their two neighbours given separately: out[i] = mid[i] | (prev & next) with
