@@ -83,10 +83,13 @@ def parse(argv=None):
     ap.add_argument("--one-stream", action="store_true",
                     help="A/B: every kernel of a pass on ONE stream (rounds 1-3); default: the front of a pass (pack + close + smoothing) on "
                          "a second stream, so that it runs under the marching-cubes chain of the pass before")
+    ap.add_argument("--equal-slices", action="store_true",
+                    help="A/B (N > 1): Z slabs of equal slice counts (rounds 1-3); default: slabs of equal work, from one pass's vertex counts")
     ap.add_argument("--read-every-pass", action="store_true",
                     help="A/B: the host reads the counters of a pass before it enqueues the next one (the GPU idles meanwhile)")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="edge of the cube the CPU oracle is timed on (default: the workload itself)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="worker processes of the all-core CPU leg (-1: min(16, cores); 0 / 1: skip it)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle, print its JSON object, touch no GPU")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run SHA-256 check of the mesh against the golden fixtures")
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the second block on BASELINE configs[4] (2048x2048x4096, strong scaling; at N = 1 its single-GPU time)")
@@ -722,6 +725,25 @@ def run(args, world, cpu=None):
         res = None
         for _ in range(2):          # allocator priming (untimed, like the warm-up): the first passes grow torch's memory pool
             res = step()
+        cuts_note = None
+        if job is not None and world > 1 and not args.equal_slices:
+            # Z slabs of equal WORK instead of equal slice counts: the per-slice vertex counts of the pass just made (all-gathered)
+            # weigh the marching-cubes chain's share of a pass against the volume-sized kernels'; every rank computes the same cuts
+            share = min(0.5, 0.29 * 1024.0 / float(y * x) ** 0.5)          # chain / pass on one GPU: 0.29 at 1024^2 slices, 0.15 at 2048^2
+            cuts = job.work_balanced_cuts(depths, share, align=4)
+            cuts_note = {"z_cuts": cuts, "equal_slices_would_be": list(job.cuts), "surface_share_assumed": round(share, 3)}
+            if cuts != job.cuts:
+                res = None
+                job = slab.SlabJob(z, y, x, comm, z_cuts=cuts)
+                mask = None
+                free_memory()
+                mask = pipeline.ellipsoid_mask(z, y, x, dev, job.z0, job.z1).view(torch.uint8)
+                collect = job.result
+                workload = "%dx%dx%d ellipsoid stack, %d Z-slabs of %d..%d slices (equal work; halos over %s)" % (
+                    x, y, z, world, job.thinnest, max(b - a for a, b in zip(cuts, cuts[1:])),
+                    ("RCCL" + (" C API, compute stream" if hasattr(comm, "close") else "")) if args.backend == "nccl" else "gloo")
+                for _ in range(2):
+                    res = step()
         if warmup:
             res = steps_in_order(warmup)
         if comm is not None:
@@ -739,7 +761,7 @@ def run(args, world, cpu=None):
             td.all_reduce(t, op=td.ReduceOp.MAX)
             dt = float(t.item())
         return {"ms": dt / max(steps, 1) * 1e3, "dt": dt, "res": res, "job": job, "mask": mask, "depths": depths, "step": step,
-                "workload": workload, "parallelism": parallelism, "n0": n0}
+                "workload": workload, "parallelism": parallelism, "n0": n0, "cuts": cuts_note}
 
     def verify(shape, blk, keep_single=False):
         """Is the mesh of this run the reference's?  SHA-256 of the WHOLE vertex / face arrays -- a Z-slab job forms them rank
@@ -841,6 +863,8 @@ def run(args, world, cpu=None):
         mx = torch.tensor([st["seconds"], st["bytes_sent"]], dtype=torch.float64, device=rdev)
         td.all_reduce(mx, op=td.ReduceOp.MAX)
         comm_out = dict(comm_info)
+        if blk.get("cuts"):
+            comm_out["slabs"] = blk["cuts"]
         comm_out.update({
             "halo_bytes_per_pass_all_ranks": int(agg[0].item() / steps), "halo_bytes_per_pass_max_rank": int(mx[1].item() / steps),
             "comm_calls_per_pass_per_rank": round(agg[1].item() / steps / world, 1),
@@ -989,7 +1013,7 @@ def run(args, world, cpu=None):
         ent = {"workload": "%s%s" % (nb["workload"], " (BASELINE configs[4])" if ns_shape == WORKLOADS["cfg5"] else ""),
                "scaling": "strong", "n_gpus": world, "steps": k_ns, "ms_per_step": round(nb["ms"], 3),
                "value": round(ns_shape[0] * ns_shape[1] * ns_shape[2] / (nb["ms"] * 1e-3) / 1e6, 1), "unit": "Mvoxels/s",
-               "numbering": {"deferred_passes": nb["job"].deferred_passes, "redone": nb["job"].deferred_redone}}
+               "numbering": {"deferred_passes": nb["job"].deferred_passes, "redone": nb["job"].deferred_redone}, "slabs": nb.get("cuts")}
         if not args.no_parity:
             par, single_ms = verify(ns_shape, nb, keep_single=True)
             ent.update(par)
@@ -1037,10 +1061,20 @@ def main(argv=None):
         # a rank of a multi-GPU run: supervise a worker child (this process never initialises the GPU, so this is a child
         # process, not an exec of a GPU process)
         return supervise([sys.executable, os.path.abspath(__file__)] + list(argv), os.environ)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_sample, args.cpu_workers if args.cpu_workers >= 0 else min(16, os.cpu_count() or 1))), flush=True)
+        return 0
     cpu = None
     if plan[1] == 1 and not args.rehearse_dist and not args.no_cpu_baseline:
-        # before anything touches the GPU: the all-core leg forks a process pool
-        cpu = cpu_baseline(args.cpu_sample, args.cpu_workers if args.cpu_workers >= 0 else min(16, os.cpu_count() or 1))
+        # In a CHILD process, started before this one touches the GPU: the oracle's 1024^3 run holds ~25 GB for a while and its
+        # all-core leg forks a pool -- neither belongs in the address space the host-to-host measurements below page their arrays
+        # into (in-process, the first create -> smooth -> extract of the classes took 170 ms instead of 137)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", str(args.cpu_sample),
+                            "--cpu-workers", str(args.cpu_workers)], stdout=subprocess.PIPE, text=True)
+        try:
+            cpu = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+        except Exception:       # noqa: BLE001
+            cpu = {"error": "the CPU baseline child left with code %d" % r.returncode}
     return run(args, plan[1], cpu)
 
 

@@ -529,18 +529,48 @@ def slab_range(gz, rank, world):
     return z0, z0 + base + (1 if rank < rem else 0)
 
 
+def balanced_cuts(weights, world, min_slices=1):
+    """Z cuts [0 = c_0 < c_1 < .. < c_world = gz] that give every rank about the same total WEIGHT (one number per slice: its
+    share of a pass's time) instead of the same number of slices; every slab keeps at least min_slices slices.  Deterministic:
+    every rank computes the same cuts from the same (all-gathered) weights."""
+    w = np.maximum(np.asarray(weights, dtype=np.float64), 0.0)
+    gz = len(w)
+    if world < 1 or gz < world * max(min_slices, 1):
+        raise ValueError("%d slices cannot be cut into %d slabs of at least %d" % (gz, world, min_slices))
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cum, total * r / world, side="left")) if total > 0 else gz * r // world
+        if c > 0 and c <= gz and abs(cum[c - 1] - total * r / world) <= abs(cum[min(c, gz)] - total * r / world):
+            c -= 1                                               # the nearer of the two candidates
+        c = max(c, cuts[-1] + min_slices)                        # room for this slab ...
+        c = min(c, gz - (world - r) * min_slices)                # ... and for those above
+        cuts.append(c)
+    cuts.append(gz)
+    return cuts
+
+
 class SlabJob:
     """One rank's share of: close ends -> smooth -> field -> marching cubes -> global mesh numbering."""
 
-    def __init__(self, gz, ny, nx, comm, engine=None, iterations=3, create_manifold=True, close_ends=True):
+    def __init__(self, gz, ny, nx, comm, engine=None, iterations=3, create_manifold=True, close_ends=True, z_cuts=None):
+        """z_cuts: world + 1 ascending slice indices from 0 to gz -- rank r owns [z_cuts[r], z_cuts[r + 1]) -- or None: equal
+        numbers of slices (slab_range).  Every rank must pass the same cuts (balanced_cuts / SlabJob.work_balanced_cuts give them)."""
         self.gz, self.ny, self.nx = gz, ny, nx
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
-        self.z0, self.z1 = slab_range(gz, self.rank, self.world)
+        if z_cuts is None:
+            z_cuts = [slab_range(gz, r, self.world)[0] for r in range(self.world)] + [gz]
+        self.cuts = [int(c) for c in z_cuts]
+        if len(self.cuts) != self.world + 1 or self.cuts[0] != 0 or self.cuts[-1] != gz or any(b <= a for a, b in zip(self.cuts, self.cuts[1:])):
+            raise ValueError("z_cuts must be %d ascending slice indices from 0 to %d" % (self.world + 1, gz))
+        self.z0, self.z1 = self.cuts[self.rank], self.cuts[self.rank + 1]
         self.eng = engine or HipEngine()
         self.iterations, self.create_manifold, self.close_ends = iterations, create_manifold, close_ends
         self.halo = 2 * (self.iterations + (1 if create_manifold else 0)) + 2
-        if self.z1 - self.z0 < self.halo + 1 and self.world > 1:
+        self.thinnest = min(b - a for a, b in zip(self.cuts, self.cuts[1:]))
+        if self.thinnest < self.halo + 1 and self.world > 1:
             raise ValueError("slab thinner than the halo (%d slices): use fewer ranks" % self.halo)
         self.active = None
         self.created = self.smoothed = self.mesh = None     # this rank's share of the last run(), for the consumers below
@@ -621,7 +651,7 @@ class SlabJob:
         if self.world > 1 and self.close_ends and hasattr(e, "pack_closed_slab") and mask.dtype in (torch.uint8, torch.bool):
             # one exchange of ORIGINAL edge slices instead of two (stencil neighbours, then closed halos): a joint decision,
             # so it goes by the thinnest slab of the job, not by this rank's
-            merged = (SPLIT_PACK and self.gz // self.world >= MERGED_MIN and hasattr(c, "exchange_async")
+            merged = (SPLIT_PACK and self.thinnest >= MERGED_MIN and hasattr(c, "exchange_async")
                       and self.nx % 16 == 0 and pipeline.PACK_CLOSE_FUSED)
             fused = e.pack_closed_slab(mask.view(torch.uint8) if mask.dtype == torch.bool else mask, Hu, c, first, last, (H, Hu), merged)
         if fused is not None:
@@ -930,15 +960,51 @@ class SlabJob:
         c = self.eng.slice_counts(vol)
         if not torch.is_tensor(c):
             c = torch.as_tensor(np.asarray(c, dtype=np.int64))
-        room = -(-self.gz // self.world)
-        mine = torch.zeros(room, dtype=torch.int64, device=c.device)
-        mine[: c.shape[0]] = c
-        parts = self.comm.all_gather(mine)
-        out = []
-        for r in range(self.world):
-            a, b = slab_range(self.gz, r, self.world)
-            out.append(parts[r][: b - a].cpu().numpy())
-        return np.concatenate(out)
+        return self._gather_per_slice(c)
+
+    def _gather_per_slice(self, mine):
+        """One int64 per owned slice on every rank -> the (gz,) array of the whole stack on every rank (one all-gather)."""
+        room = max(b - a for a, b in zip(self.cuts, self.cuts[1:]))
+        padded = torch.zeros(room, dtype=torch.int64, device=mine.device)
+        padded[: mine.shape[0]] = mine
+        parts = self.comm.all_gather(padded)
+        return np.concatenate([parts[r][: self.cuts[r + 1] - self.cuts[r]].cpu().numpy() for r in range(self.world)])
+
+    def slice_vertex_counts(self, slice_depths):
+        """Vertices of the current mesh per slice of the whole stack (a vertex between two planes counts for the lower one) ->
+        int64 (gz,) on every rank: what the surface-sized kernels of a pass cost, slice by slice."""
+        if self.mesh is None:
+            raise RuntimeError("run() first")
+        verts = self.mesh[0]
+        dev = verts.device
+        d = np.asarray(slice_depths, dtype=np.float64)
+        z = verts[:, 0].detach().cpu().numpy().astype(np.float64)
+        if len(d):
+            # z' of padded plane Z is the cumulative depth in front of slice Z - 1 (surface_extractor.py:82-113): invert it
+            adj = np.concatenate([[d[0]], d, [d[-1]]])
+            cum = np.cumsum(np.concatenate([[0.0], adj]))
+            plane = np.searchsorted(np.asarray(cum, np.float32).astype(np.float64), z, side="right") - 1
+            sl = np.clip(plane, 0, self.gz - 1)                  # (padded plane Z' = slice Z' - 1 after the -1 shift: already slice units)
+        else:
+            sl = np.clip(np.floor(z).astype(np.int64), 0, self.gz - 1)
+        counts = np.bincount(np.clip(sl - self.z0, 0, self.z1 - self.z0 - 1), minlength=self.z1 - self.z0).astype(np.int64)
+        return self._gather_per_slice(torch.from_numpy(counts).to(dev))
+
+    def work_balanced_cuts(self, slice_depths, surface_share=0.25, align=1):
+        """Cuts for a NEW job on stacks like the current one: a slice weighs 1 (the volume-sized kernels: pack, smoothing,
+        field) plus surface_share / (1 - surface_share) x its vertices relative to the mean (the marching-cubes chain).  A rank
+        in the middle of a long body holds more surface per slice than one at its ends: with equal slice counts the 8 ranks of
+        BASELINE configs[4] hold 3.0 - 3.6 M vertices each.  align: cuts are rounded to a multiple of this many slices."""
+        v = self.slice_vertex_counts(slice_depths).astype(np.float64)
+        mean = v.mean() if v.sum() > 0 else 1.0
+        k = surface_share / max(1.0 - surface_share, 1e-6)
+        cuts = balanced_cuts(1.0 + k * v / mean, self.world, max(self.halo + 1, align))
+        if align > 1:
+            inner = [int(round(c / align)) * align for c in cuts[1:-1]]
+            cand = [0] + inner + [self.gz]
+            if all(b - a >= self.halo + 1 for a, b in zip(cand, cand[1:])):
+                cuts = cand
+        return cuts
 
     def index_box(self, which="smoothed"):
         """(zmin, zmax, ymin, ymax, xmin, xmax) of the set voxels of the whole stack as np.int64, or None if it is empty

@@ -127,7 +127,9 @@ def main():
     direct = os.environ.get("TOMO_RCCL_DIRECT", "1") not in ("", "0")
     comm = SelfLoopRccl(dev, rank, world) if direct else SelfLoopComm(dev, rank, world)
     gz = world * nzr
-    job = slab.SlabJob(gz, ny, nx, comm)
+    cuts = os.environ.get("TOMO_SELFLOOP_CUTS")              # "0,606,...,4096": slabs of equal work (tools/balanced_cuts.py prints them)
+    cuts = [int(c) for c in cuts.split(",")] if cuts else None
+    job = slab.SlabJob(gz, ny, nx, comm, z_cuts=cuts)
     mask = pipeline.ellipsoid_mask(gz, ny, nx, dev, job.z0, job.z1).view(torch.uint8)
     depths = np.full(gz, 1.0)
     if direct and 0 < rank < world - 1:
