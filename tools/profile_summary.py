@@ -51,7 +51,11 @@ def find(d, sub):
 fk = "field_tile_kernel"
 fkb, wkb = find(fetch, fk), find(write, fk)
 field_us = [sum(v) / len(v) for k, v in acc.items() if fk in k][0]
+import hashlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pmcj = {"kernel": fk, "command": "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras",
+        # bench.py uses these counter bytes only for the build of the kernel they were measured on
+        "field_hip_sha256": hashlib.sha256(open(os.path.join(ROOT, "tomography_3d_reconstructor_amd", "csrc", "field.hip"), "rb").read()).hexdigest(),
         "fetch_size_kb_raw": fkb, "write_size_kb": wkb, "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024,
         "correction": "reads x2 (gfx950 FETCH_SIZE counts half of the bytes of coalesced reads; calibrated in round 1 on "
                       "pack16_kernel's exact 1 GiB -- pack_close_kernel reads 34/32 of it), writes exact", "kernel_us_in_trace": field_us}
@@ -67,11 +71,11 @@ for n, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
 md.append("\n(`at::native::*` kernels are the synthetic-mask generation before the timed region.)\n")
 md.append("\n## PMC passes (separate runs of the same command: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`), per dispatch, KB\n")
 md.append("Calibration (round 1): `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
-          "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below (`pack_close_kernel` reads 34/32 GiB: every run of 32 "
-          "slices re-reads its two neighbours).  WRITE_SIZE is exact.\n")
+          "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below (`pack_close_ho_kernel`, round 4, reads 130/128 GiB: only the outer waves of a workgroup "
+          "re-read a neighbour's slice; rounds 1-3: 34/32).  WRITE_SIZE is exact.\n")
 md.append("| kernel | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM bytes = 2*FETCH + WRITE |\n|---|---|---|---|")
-for sub in ("pack_close_kernel", "morph_wave32_kernel<4, 6", "morph_wave32_kernel<4, 5", fk, "mc_classify_bits_kernel", "mc3_list_kernel", "mc3_eval_kernel",
-            "mc3_vertices_kernel", "rocprim", "uq3_rank_kernel", "mc3_faces_kernel"):
+for sub in ("pack_close_ho_kernel", "pack_close_kernel", "morph_wave32_kernel<4, 6", "morph_wave32_kernel<4, 5", fk, "mc_classify_bits_kernel", "mc3_list_kernel", "mc3_eval_kernel",
+            "mc3_vertices_kernel", "uq3_sortrank_kernel<2560>", "rocprim", "uq3_rank_kernel", "mc3_faces_kernel"):
     a, b = find(fetch, sub), find(write, sub)
     if a is not None and b is not None:
         md.append("| `%s` | %.0f | %.0f | %.3e |" % (sub, a, b, (2 * a + b) * 1024))
