@@ -656,19 +656,28 @@ def run(args, world, cpu=None):
             pend = nxt
         if pend is not None:
             r = pend.result()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pend = None
-        for _ in range(steps):
-            nxt = one_pass_submit(m, d, not args.one_stream)
+        best = None
+        for _rep in range(2):                               # the better of two timed runs (a denominator must not carry a hiccup)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pend = None
+            for _ in range(steps):
+                nxt = one_pass_submit(m, d, not args.one_stream)
+                if pend is not None:
+                    r = pend.result()
+                pend = nxt
+                beat[0] = time.monotonic()
             if pend is not None:
                 r = pend.result()
-            pend = nxt
-            beat[0] = time.monotonic()
-        if pend is not None:
-            r = pend.result()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / max(steps, 1) * 1e3, r
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            best = dt1 if best is None else min(best, dt1)
+        if os.environ.get("TOMO_BENCH_DEBUG"):
+            print("single_gpu_block %r: %d steps in %.1f ms; allocator: %s" % (
+                shape, steps, best * 1e3, {k: v for k, v in torch.cuda.memory_stats(dev).items()
+                                           if k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "reserved_bytes.all.current")}),
+                  file=sys.stderr, flush=True)
+        return best / max(steps, 1) * 1e3, r
 
     def fits_one_gpu(shape):
         free, _total = torch.cuda.mem_get_info(dev)
