@@ -293,7 +293,7 @@ int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t *idx, int
 /* ABI 6, the default since round 4: the same stage -- np.unique(axis=0)'s order inside the buckets, rows, table, the count of
  * places that do not ascend strictly (tot[4]), the rows on z' == z_top (tot[7]) -- in ONE hand-written kernel (a workgroup per
  * segment: wave bitonic + merge rounds in LDS, rows gathered in sorted order), no library primitive, no workspace; `idx` of
- * tomo_mc3_vertices may be NULL for it.  A segment longer than 4 096 entries (2 048 for the clamped run of a padded stack's
+ * tomo_mc3_vertices may be NULL for it.  A segment longer than 4 096 entries (1 024 for the clamped run of a padded stack's
  * first slices) sets bit 8 of tot[3]: repeat the stage with tomo_mc3_sort_rank_top (after zeroing tot[3], tot[4], tot[7]). */
 int tomo_mc3_sort_rank_fused(const float *vrec, const uint32_t *keys, int64_t cap_v, int Nz, int Ny, uint32_t *slice_tab,
                              unsigned long long *tot, float *uniq, int32_t *table, float z_top, void *stream);

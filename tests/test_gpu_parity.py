@@ -940,7 +940,7 @@ def test_planes_sorted_in_bands_of_owner_rows_vs_oracle(dev, ny, kind):
     tomo_sort_band; mc3_bands_kernel) -- the order inside a plane is local to a row.  Tall, thin stacks either side of the switch:
     a body whose surface crosses every band boundary (`body`: a narrow one, its flat faces fit the hand-written sort's LDS;
     `wide`: ~40 000 vertices between two planes, the library path), a mask in the first slice (the clamped run is merged with
-    the first plane, now several segments: `first` takes the library path, `first_thin` -- a line of pixels -- the kernel's
+    the first plane, now several segments: `first` takes the library path, `first_thin` -- a short line of pixels -- the kernel's
     two-pass (x', then y') order), noise (rows with hundreds of vertices, ties).  Same mesh as the oracle, and -- except for
     noise, which may tie across buckets -- without the general sort."""
     nz, nx = 5, 48
@@ -951,6 +951,8 @@ def test_planes_sorted_in_bands_of_owner_rows_vs_oracle(dev, ny, kind):
     else:
         half = {"body": 0.03, "first_thin": 0.01}.get(kind, 0.4) * nx           # half width of the body along x
         disc = ((yy - ny / 2) / (0.47 * ny)) ** 2 + ((xx - nx / 2) / half) ** 2 <= 1.0
+        if kind == "first_thin":                                                  # a short line of pixels across the band boundary at row 512:
+            disc = ((yy - 0.75 * ny) / (0.15 * ny)) ** 2 + ((xx - nx / 2) / half) ** 2 <= 1.0    # its clamped run fits the kernel's 1 024
         v = np.zeros((nz, ny, nx), bool)
         v[(0 if kind.startswith("first") else 1):4] = disc
         v[2, ::37, 5:nx - 5:3] ^= True                                   # specks: vertices between the planes, in every band

@@ -547,7 +547,7 @@ TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx
 }
 
 // ------------------------------------------------------------------------------------------ mc3: sort + rank in ONE kernel (round 4)
-// The default path of the unique stage since round 4: 100 + 5 + 5 us at 1024^3 against 83 + 5 + 45 for rocPRIM's segmented sort +
+// The default path of the unique stage since round 4: 97 + 5 us at 1024^3 against 83 + 5 + 45 for rocPRIM's segmented sort +
 // uq3_merge_kernel + uq3_rank_kernel, which stay as the path for segments too long for LDS (pipeline.FUSED_SORT /
 // TOMO_FUSED_SORT=0: the A/B switch).  One workgroup per sort segment -- a plane band or a between-plane bucket, the segments of
 // mc3_bands_kernel:
@@ -569,17 +569,18 @@ TOMO_API int tomo_mc3_sort_rank(const float *vrec, uint32_t *keys, uint32_t *idx
 // (the voxelised surface has terraces: hundreds of exactly equal keys in one bin); one WAVE per segment, everything in registers
 // (a bitonic network over up to 64 words per lane): 149 + 113 (200 VGPRs, 64-bit compare-exchanges at VALU rate); this version
 // with 2 560 entries in the first launch (46 KiB: three workgroups per CU, every segment of the bench workloads): 104 + 5, and
-// with the first and the last slices dispatched first: 100 + 5.  All of them are bound by chains of dependent LDS accesses
-// behind barriers.  A ticket + __threadfence per workgroup for a "last one checks the seams" cost 480 us (the fence writes the
+// with the first and the last slices dispatched first: 100 + 5; ONE launch with 2 048 entries (36 KiB, four workgroups per CU) in
+// which a longer segment is sorted as two halves + one merge (this version): 97 -- those ~130 workgroups are its critical path.
+// All of them are bound by chains of dependent LDS accesses behind barriers.  A ticket + __threadfence per workgroup for a "last one checks the seams" cost 480 us (the fence writes the
 // L2 back, 3 000 times): hence the separate seam kernel.
 // The clamped run of a padded stack -- the between-plane bucket of slice 0 and the plane of slice 1 have the SAME z' when the
 // depth map clamps z < 0 to 0 (uq3_merge_kernel merges them in the rocPRIM path) -- is ONE segment here, ordered by (y', x')
-// through two stable passes (x', then y').  Segments beyond SR_CAP entries (half as many for the clamped run) set bit 8 of
+// through two stable passes (x', then y').  Segments beyond SR_CAP entries (1 024 for the clamped run) set bit 8 of
 // tot[3]: the host repeats the stage on the rocPRIM path and remembers it for this geometry (pipeline._MC3_LARGE).
 #define SR_THREADS 256
 #define SR_E 8                       // words per thread and round
-#define SR_CAP 4096
-#define SR_CAP_SMALL 2560             // the variant every segment goes through first (46 KiB of LDS: three workgroups per CU)
+#define SR_CAP 4096                  // longest segment the kernel takes (two halves)
+#define SR_HALF 2048                 // entries it sorts in one go (36 KiB of LDS: four workgroups per CU)
 #define SR_PAD(i) ((i) + ((i) >> 3))
 #define SR_WORDS(cap) ((cap) + ((cap) >> 3))
 #define SR_RUN (64 * SR_E)           // words a wave sorts in registers
@@ -715,16 +716,17 @@ __device__ static u64 *sr_sort(u64 *a, u64 *b, const int n, Make make)
     return src;
 }
 
-// CAP entries of LDS per workgroup (18 B each: the two padded sort buffers, later the gathered rows).  The chain launches the
-// SR_CAP_SMALL variant for every segment and the SR_CAP variant behind it for the segments the first one left (it skips the
-// others at once: 5 us when there are none).
-template <int CAP>
+// SR_HALF entries of LDS per workgroup (18 B each: the two padded sort buffers, later the gathered rows): 36 KiB, four workgroups
+// per CU.  A segment of up to SR_HALF entries is sorted in one go; a longer one (up to SR_CAP: the between-plane buckets at the poles
+// of a closed body) as two halves -- the first half's sorted words wait in registers while the second is sorted -- then ONE merge
+// whose 16 consecutive outputs per thread go straight to the gathers (no room in LDS for a merged copy: a row's predecessor comes
+// from the neighbouring lane).  Those workgroups are dispatched first and overlap the rest.
 __global__ __launch_bounds__(SR_THREADS) void uq3_sortrank_kernel(const float4 *__restrict__ vrec, const u32 *__restrict__ keys,
                                                                   const u32 *__restrict__ offsets, const int NB, const int Nz,
                                                                   float *__restrict__ uniq, int32_t *__restrict__ table,
                                                                   u64 *__restrict__ tot, const float z_top)
 {
-    constexpr int EP = CAP / SR_THREADS;
+    constexpr int CAP = SR_HALF, EP = CAP / SR_THREADS;
     extern __shared__ __attribute__((aligned(16))) u64 s_buf[];   // 2 * SR_WORDS(CAP) words
     u64 *const s_a = s_buf, *const s_b = s_buf + SR_WORDS(CAP);
     float4 *const s_rows = (float4 *)s_buf;                       // (after the sort: the rows in final order)
@@ -755,15 +757,81 @@ __global__ __launch_bounds__(SR_THREADS) void uq3_sortrank_kernel(const float4 *
             __syncthreads();
         }
     }
-    // which variant takes this segment (the clamped run keeps its first order in one buffer: half the capacity)
-    constexpr int UCAP = CAP / 2 / SR_RUN * SR_RUN, UCAP_SMALL = SR_CAP_SMALL / 2 / SR_RUN * SR_RUN;   // whole runs per half buffer
-    const int mine = uni ? UCAP : CAP, below = CAP > SR_CAP_SMALL ? (uni ? UCAP_SMALL : SR_CAP_SMALL) : 0;
-    if (n > mine) {
-        if (CAP >= SR_CAP && tid == 0) atomicOr((unsigned long long *)&tot[3], 8ull);   // too long for LDS: the host takes the rocPRIM path
-        n = 0;
+    constexpr int UCAP = CAP / 2 / SR_RUN * SR_RUN;               // the clamped run keeps its first order in one buffer: whole runs per half
+    if (n > (uni ? UCAP : SR_CAP)) {
+        if (tid == 0) atomicOr((unsigned long long *)&tot[3], 8ull);            // too long: the host takes the rocPRIM path
+        return;
     }
-    if (n <= below) n = 0;                                        // the smaller variant has done it
     if (n == 0) return;
+    if (n > CAP) {
+        // ---- a long segment: two half sorts, one merge, rows straight from the merge
+        const int nB = n - CAP;
+        const u64 *sa = sr_sort(s_a, s_b, CAP, [=](int i) { return ((u64)keys[o0 + i] << 32) | (u32)i; });
+        u64 ra[EP], rb[EP];
+#pragma unroll
+        for (int e = 0; e < EP; e++) ra[e] = sa[SR_PAD(tid + SR_THREADS * e)];
+        __syncthreads();
+        const u64 *sb = sr_sort(s_a, s_b, nB, [=](int i) { return ((u64)keys[o0 + CAP + i] << 32) | (u32)(CAP + i); });
+#pragma unroll
+        for (int e = 0; e < EP; e++) rb[e] = sb[SR_PAD(min(tid + SR_THREADS * e, nB - 1))];
+        __syncthreads();
+        u64 *const M = s_buf;                                    // [first half | second half], one word of padding per 16
+#define SR_MP(i) ((i) + ((i) >> 4))
+#pragma unroll
+        for (int e = 0; e < EP; e++) {
+            const int i = tid + SR_THREADS * e;
+            M[SR_MP(i)] = ra[e];
+            if (i < nB) M[SR_MP(CAP + i)] = rb[e];
+        }
+        float4 *const s_tail = (float4 *)(s_buf + SR_MP(SR_CAP) + 2);           // the last row of every wave (behind the merge area)
+        __syncthreads();
+        constexpr int EO = SR_CAP / SR_THREADS;                  // 16 consecutive outputs per thread
+        const int g0 = tid * EO < n ? tid * EO : n;              // (threads past the end merge nothing)
+        int lo = g0 - nB > 0 ? g0 - nB : 0, hi = g0 < CAP ? g0 : CAP;
+        while (lo < hi) {                                         // the merge path crosses diagonal g0 at (lo, g0 - lo)
+            const int mid = (lo + hi) >> 1;
+            if (M[SR_MP(mid)] < M[SR_MP(CAP + g0 - 1 - mid)]) lo = mid + 1; else hi = mid;
+        }
+        int ia = lo, ib = g0 - lo;
+        u64 va = ia < CAP ? M[SR_MP(ia)] : ~0ull, vb = ib < nB ? M[SR_MP(CAP + ib)] : ~0ull;
+        float4 r[EO];
+#pragma unroll
+        for (int k = 0; k < EO; k++) {
+            const bool ta = va < vb;
+            const u64 w = ta ? va : vb;
+            ia += ta ? 1 : 0; ib += ta ? 0 : 1;
+            const bool ok = ta ? ia < CAP : ib < nB;
+            const u64 nw = ok ? M[SR_MP(ta ? ia : CAP + ib)] : ~0ull;
+            va = ta ? nw : va; vb = ta ? vb : nw;
+            r[k] = vrec[o0 + (w == ~0ull ? 0u : (u32)w)];        // the gather is issued as soon as its place is known
+        }
+#pragma unroll
+        for (int k = 0; k < EO; k++) asm volatile("" : "+v"(r[k].x), "+v"(r[k].y), "+v"(r[k].z), "+v"(r[k].w));
+        // the row in front of this thread's first one: the last row of the lane below (of the wave below for lane 0)
+        float4 below;
+        below.x = __shfl_up(r[EO - 1].x, 1, 64); below.y = __shfl_up(r[EO - 1].y, 1, 64); below.z = __shfl_up(r[EO - 1].z, 1, 64);
+        if (lane == 63) s_tail[wave] = r[EO - 1];
+        __syncthreads();
+        if (lane == 0 && wave > 0) below = s_tail[wave - 1];
+        u32 nviol = 0, ntop = 0;
+        float4 prev = below;
+#pragma unroll
+        for (int k = 0; k < EO; k++) {
+            const int i = tid * EO + k;
+            if (i < n && (u64)(o0 + i) < nv) {
+                if (i > 0 && !rec_less(prev, r[k])) nviol++;
+                typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                *(f3u *)(uniq + 3 * (int64_t)(o0 + i)) = (f3u){r[k].x, r[k].y, r[k].z};
+                table[__float_as_uint(r[k].w)] = (int32_t)(o0 + i);
+                if (r[k].x == z_top) ntop++;
+            }
+            prev = r[k];
+        }
+        nviol = wave_sum(nviol); ntop = wave_sum(ntop);
+        if (lane == 0 && nviol) atomicAdd((unsigned long long *)&tot[4], (unsigned long long)nviol);
+        if (lane == 0 && ntop) atomicAdd((unsigned long long *)&tot[7], (unsigned long long)ntop);
+        return;
+    }
     const u64 *sorted;
     const u32 *first = nullptr;                                   // (clamped run) position after the first pass
     if (!uni) {
@@ -845,17 +913,9 @@ TOMO_API int tomo_mc3_sort_rank_fused(const float *vrec, const uint32_t *keys, i
     if (nseg >= 0x7fffffffll) return TOMO_E_SIZE;
     const u32 *offsets = slice_tab + 2 * ((int64_t)Nz + 1);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    const size_t lds_small = 2 * SR_WORDS(SR_CAP_SMALL) * sizeof(u64), lds_big = 2 * SR_WORDS(SR_CAP) * sizeof(u64);
-    if (!attr_set) {                                                   // 72 KiB of dynamic LDS needs the opt-in (idempotent; a race only repeats it)
-        if (hipFuncSetAttribute((const void *)uq3_sortrank_kernel<SR_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big) != hipSuccess)
-            return TOMO_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((uq3_sortrank_kernel<SR_CAP_SMALL>), dim3((unsigned)nseg), dim3(SR_THREADS), lds_small, s, (const float4 *)vrec,
-                       (const u32 *)keys, offsets, NB, Nz, uniq, table, (u64 *)tot, z_top);
-    hipLaunchKernelGGL((uq3_sortrank_kernel<SR_CAP>), dim3((unsigned)nseg), dim3(SR_THREADS), lds_big, s, (const float4 *)vrec,
-                       (const u32 *)keys, offsets, NB, Nz, uniq, table, (u64 *)tot, z_top);
+    const size_t lds = 2 * SR_WORDS(SR_HALF) * sizeof(u64);
+    hipLaunchKernelGGL(uq3_sortrank_kernel, dim3((unsigned)nseg), dim3(SR_THREADS), lds, s, (const float4 *)vrec, (const u32 *)keys,
+                       offsets, NB, Nz, uniq, table, (u64 *)tot, z_top);
     hipLaunchKernelGGL(uq3_seams_kernel, dim3((unsigned)ceil_div64(nseg, 256)), dim3(256), 0, s, (const float *)uniq, offsets, (int)nseg,
                        (u64 *)tot);
     return tomo_status();
