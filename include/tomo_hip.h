@@ -48,6 +48,8 @@ void tomo_host_mc_centre_offset(const double *h_v8, double *h_out3); /* (x,y,z) 
  * device-volume cache of the drop-in classes uses it to make sure a host array the caller could write to still holds
  * what was uploaded (voxel_processor.py:84 / surface_extractor.py:43-46 read the array they are handed). */
 int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_t *h_out);
+/* the same with the implementation named (ABI 6): 0 = the fastest the CPU offers (AVX2), 1 = the portable loop; one digest */
+int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out);
 /* Page a freshly allocated HOST buffer in on `nthreads` threads (one byte per 4 KiB page is written; content unspecified):
  * the 1 B/voxel arrays the drop-in classes hand back (voxel_processor.py:46, :84 create them with np.stack / .copy()) cost
  * ~65 ms per GiB of page faults when a single thread -- or the DMA engine's pinning pass -- touches them first. */

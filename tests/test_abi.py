@@ -97,6 +97,21 @@ def test_host_checksum_sees_every_byte():
     assert _devcache.checksum(np.zeros(0, bool)) == _devcache.checksum(np.zeros((0, 4), bool))
 
 
+def test_host_checksum_avx2_and_portable_loops_agree():
+    """tomo_host_checksum_impl: the AVX2 stripes and the portable loop give ONE digest (ragged sizes, several threads)."""
+    import ctypes
+    import numpy as np
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 63, 64, 65, 1023, 1024, 1025, (1 << 20) - 1, 1 << 20, (1 << 20) + 77, 3 * (1 << 20) + 12345):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        o0, o1, o2 = (ctypes.c_uint64 * 2)(), (ctypes.c_uint64 * 2)(), (ctypes.c_uint64 * 2)()
+        assert L.tomo_host_checksum_impl(a.ctypes.data if n else None, n, 3, 0, o0) == 0
+        assert L.tomo_host_checksum_impl(a.ctypes.data if n else None, n, 1, 1, o1) == 0
+        assert L.tomo_host_checksum(a.ctypes.data if n else None, n, 2, o2) == 0
+        assert tuple(o0) == tuple(o1) == tuple(o2), n
+
+
 def test_devcache_never_returns_a_stale_volume(monkeypatch):
     """A cached device copy is used only for an array that is write-protected or verified byte for byte."""
     import numpy as np

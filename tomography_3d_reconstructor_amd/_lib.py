@@ -26,6 +26,7 @@ SIGNATURES = {
     "tomo_host_mc_edge_offset": (_c_d, [_c_d, _c_d]),
     "tomo_host_mc_centre_offset": (None, [_c_p, _c_p]),
     "tomo_host_checksum": (_c_i, [_c_p, _c_i64, _c_i, _c_p]),
+    "tomo_host_checksum_impl": (_c_i, [_c_p, _c_i64, _c_i, _c_i, _c_p]),
     "tomo_host_touch": (_c_i, [_c_p, _c_i64, _c_i]),
     "tomo_host_gather": (_c_i, [_c_p, _c_i64, _c_i64, _c_p, _c_i]),
     "tomo_host_sha256_init": (_c_i, [_c_p]),

@@ -33,7 +33,42 @@ inline uint64_t avalanche(uint64_t h)
 
 // digest of one chunk (n bytes, n <= CHUNK); `index` makes equal chunks at different places differ
 
-void chunk_digest(const uint8_t *p, int64_t n, uint64_t index, uint64_t out[2])
+#if defined(__x86_64__)
+// the stripes of a chunk on AVX2: the 8 lanes are two vectors of four 64-bit words; the same wrapping arithmetic as the scalar
+// loop below (adds commute), so the digest does not depend on which one ran.  -> stripes done
+__attribute__((target("avx2"))) int64_t chunk_stripes_avx2(const uint8_t *q, int64_t nstripes, uint64_t acc[LANES], uint64_t key[LANES])
+{
+    __m256i a0 = _mm256_loadu_si256((const __m256i *)&acc[0]), a1 = _mm256_loadu_si256((const __m256i *)&acc[4]);
+    __m256i k0 = _mm256_loadu_si256((const __m256i *)&key[0]), k1 = _mm256_loadu_si256((const __m256i *)&key[4]);
+    const __m256i p1 = _mm256_set1_epi64x((long long)P1), c = _mm256_set1_epi64x(0x9E3779B1ll);
+    for (int64_t s = 0; s < nstripes; s++, q += 8 * LANES) {
+        const __m256i w0 = _mm256_loadu_si256((const __m256i *)q), w1 = _mm256_loadu_si256((const __m256i *)(q + 32));
+        const __m256i d0 = _mm256_xor_si256(w0, k0), d1 = _mm256_xor_si256(w1, k1);
+        a0 = _mm256_add_epi64(a0, _mm256_permute4x64_epi64(w0, 0xB1));              // acc[j ^ 1] += w[j]
+        a1 = _mm256_add_epi64(a1, _mm256_permute4x64_epi64(w1, 0xB1));
+        a0 = _mm256_add_epi64(a0, _mm256_mul_epu32(d0, _mm256_srli_epi64(d0, 32)));  // acc[j] += lo32(d) * hi32(d)
+        a1 = _mm256_add_epi64(a1, _mm256_mul_epu32(d1, _mm256_srli_epi64(d1, 32)));
+        k0 = _mm256_add_epi64(k0, p1);
+        k1 = _mm256_add_epi64(k1, p1);
+        if ((s & 15) == 15) {                                                        // acc = (acc ^ (acc >> 47) ^ key) * 0x9E3779B1
+            __m256i t0 = _mm256_xor_si256(_mm256_xor_si256(a0, _mm256_srli_epi64(a0, 47)), k0);
+            __m256i t1 = _mm256_xor_si256(_mm256_xor_si256(a1, _mm256_srli_epi64(a1, 47)), k1);
+            a0 = _mm256_add_epi64(_mm256_mul_epu32(t0, c), _mm256_slli_epi64(_mm256_mul_epu32(_mm256_srli_epi64(t0, 32), c), 32));
+            a1 = _mm256_add_epi64(_mm256_mul_epu32(t1, c), _mm256_slli_epi64(_mm256_mul_epu32(_mm256_srli_epi64(t1, 32), c), 32));
+        }
+    }
+    _mm256_storeu_si256((__m256i *)&acc[0], a0); _mm256_storeu_si256((__m256i *)&acc[4], a1);
+    _mm256_storeu_si256((__m256i *)&key[0], k0); _mm256_storeu_si256((__m256i *)&key[4], k1);
+    return nstripes;
+}
+bool have_avx2()
+{
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+#endif
+
+void chunk_digest(const uint8_t *p, int64_t n, uint64_t index, uint64_t out[2], int impl)
 {
     uint64_t acc[LANES], key[LANES];
     for (int j = 0; j < LANES; j++) {
@@ -42,7 +77,11 @@ void chunk_digest(const uint8_t *p, int64_t n, uint64_t index, uint64_t out[2])
     }
     int64_t nstripes = n / (8 * LANES);
     const uint8_t *q = p;
-    for (int64_t s = 0; s < nstripes; s++, q += 8 * LANES) {
+    int64_t s = 0;
+#if defined(__x86_64__)
+    if (impl != 1 && have_avx2()) { s = chunk_stripes_avx2(q, nstripes, acc, key); q += s * 8 * LANES; }
+#endif
+    for (; s < nstripes; s++, q += 8 * LANES) {
         uint64_t w[LANES];
         memcpy(w, q, sizeof w);
         for (int j = 0; j < LANES; j++) {
@@ -76,7 +115,13 @@ void chunk_digest(const uint8_t *p, int64_t n, uint64_t index, uint64_t out[2])
 }  // namespace
 
 // h_out[0..1] = checksum of h_data[0 .. nbytes).  nthreads <= 0: one thread.  Returns 0 or TOMO_E_ARG.
+// impl: 0 = the fastest the CPU offers (AVX2), 1 = the portable loop; same digest (tests compare them)
+TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out);
 TOMO_API int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_t *h_out)
+{
+    return tomo_host_checksum_impl(h_data, nbytes, nthreads, 0, h_out);
+}
+TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out)
 {
     if (!h_out || nbytes < 0 || (nbytes > 0 && !h_data)) return TOMO_E_ARG;
     const uint8_t *p = (const uint8_t *)h_data;
@@ -87,7 +132,7 @@ TOMO_API int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads
     auto work = [&](int64_t c0, int64_t c1) {
         for (int64_t c = c0; c < c1; c++) {
             int64_t off = c * CHUNK, n = nbytes - off < CHUNK ? nbytes - off : CHUNK;
-            chunk_digest(p + off, n, (uint64_t)c, &dig[(size_t)c * 2]);
+            chunk_digest(p + off, n, (uint64_t)c, &dig[(size_t)c * 2], impl);
         }
     };
     if (nthreads == 1) {

@@ -18,6 +18,6 @@ export TOMO_ORACLE_LIB="$PWD/oracle/_build/libtomo_oracle_asan.so"
 export TOMO_LIB="$PWD/tomography_3d_reconstructor_amd/libtomo_host_asan.so"
 export TOMO_HOST_ONLY=1
 python -m pytest -q -x -p no:cacheprovider tests/test_oracle_golden.py tests/test_consumers_cpu.py tests/test_host_mc_cell.py \
-    tests/test_slab_cpu.py "tests/test_abi.py::test_host_checksum_sees_every_byte" \
+    tests/test_slab_cpu.py "tests/test_abi.py::test_host_checksum_sees_every_byte" "tests/test_abi.py::test_host_checksum_avx2_and_portable_loops_agree" \
     "tests/test_abi.py::test_devcache_never_returns_a_stale_volume" "tests/test_abi.py::test_host_sha256_with_a_relocatable_state_matches_hashlib" "tests/test_abi.py::test_abi_version_and_error_strings" \
     tests/test_host_helpers.py
