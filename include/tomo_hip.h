@@ -50,6 +50,12 @@ void tomo_host_mc_centre_offset(const double *h_v8, double *h_out3); /* (x,y,z) 
 int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_t *h_out);
 /* the same with the implementation named (ABI 6): 0 = the fastest the CPU offers (AVX2), 1 = the portable loop; one digest */
 int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out);
+/* ... and in two steps (ABI 6), for a buffer that arrives piece by piece (a download in pieces: piece k is digested while piece
+ * k + 1 is on the bus): the digests (2 words each) of the tomo_host_checksum_chunk_bytes()-sized chunks of a PART that starts at a
+ * chunk boundary, first_chunk = its offset / chunk size; then the fold of all chunk digests of the buffer, in order. */
+int64_t tomo_host_checksum_chunk_bytes(void);
+int tomo_host_checksum_part(const void *h_part, int64_t nbytes, int64_t first_chunk, int nthreads, int impl, uint64_t *h_dig);
+int tomo_host_checksum_fold(const uint64_t *h_dig, int64_t nchunks, int64_t nbytes, uint64_t *h_out);
 /* Page a freshly allocated HOST buffer in on `nthreads` threads (one byte per 4 KiB page is written; content unspecified):
  * the 1 B/voxel arrays the drop-in classes hand back (voxel_processor.py:46, :84 create them with np.stack / .copy()) cost
  * ~65 ms per GiB of page faults when a single thread -- or the DMA engine's pinning pass -- touches them first. */

@@ -310,3 +310,37 @@ def test_cfg1_literal_half_ellipsoid_stack(dev, tmp_path):
     assert res[0].dtype == np.float32 and res[0].tobytes() == ores[0].tobytes(), "vertices differ from the oracle"
     assert res[1].dtype == np.int64 and np.array_equal(res[1], ores[1]), "faces differ from the oracle"
     assert len(res[0]) > 10000 and abs(se.calculate_mesh_volume(*res) - ose.calculate_mesh_volume(*ores)) <= 1e-6 * ose.calculate_mesh_volume(*ores)
+
+
+def test_results_are_checksummed_while_they_download_and_verified_next_to_the_work(dev, monkeypatch):
+    """Round 4 (writeable results by default): the checksum a result needs is taken piece by piece WHILE it downloads
+    (voxel_processor._download_with_digest) and the verification of an array that comes back runs on a helper thread next to the
+    device work (with_device_volume): same digests as the one-shot checksum, an edited array is still never served from the cache."""
+    from tomography_3d_reconstructor_amd import _devcache, pipeline
+    from tomography_3d_reconstructor_amd import voxel_processor as VP
+    monkeypatch.setattr(_devcache, "WRITEABLE_RESULTS", True)
+    monkeypatch.setattr(VP, "BIG", 1 << 20)                  # the volume-sized path for a 5 MiB volume, in pieces of 1 MiB
+    monkeypatch.setattr(VP, "PIECE", 1 << 20)
+    _devcache.clear()
+    rng = np.random.default_rng(8)
+    nz, ny, nx = 37, 300, 480                                 # 5 328 000 bytes: not a whole number of pieces
+    v = np.stack(O.ellipsoid_masks(nz, ny, nx)) ^ (rng.random((nz, ny, nx)) < 0.004)
+    vp, se = VP.VoxelProcessor(), SurfaceExtractor()
+    created = vp.create_voxel_data([m.copy() for m in v], True, 0, nz, 0)
+    ent = _devcache._cache[id(created)]
+    assert created.flags.writeable and ent[2] == _devcache.checksum(created)          # the pipelined digest IS the checksum
+    assert np.array_equal(created, O.close_ends(v))
+    before = dict(_devcache.STATS)
+    sm = vp.smooth_voxel_data(created)                                                 # cached copy, verified next to the work
+    assert _devcache.STATS["hit_verified"] == before["hit_verified"] + 1 and np.array_equal(sm, O.smooth(created, 3, True))
+    created[20, 150, 200:260] ^= True                                                  # edited: the speculative result is thrown away
+    before = dict(_devcache.STATS)
+    sm2 = vp.smooth_voxel_data(created)
+    assert _devcache.STATS["miss_edited"] == before["miss_edited"] + 1 and _devcache.STATS["hit_verified"] == before["hit_verified"]
+    assert np.array_equal(sm2, O.smooth(created, 3, True))
+    depths = np.full(nz, 0.5)
+    sm2[:, :, 1::32] ^= True
+    ref = O.SurfaceExtractor().extract_manifold_surface(sm2.copy(), depths, 0.7, 0.9)
+    got = se.extract_manifold_surface(sm2, depths, 0.7, 0.9)
+    assert got[0].tobytes() == ref[0].tobytes() and np.array_equal(got[1], ref[1])
+    _devcache.clear()

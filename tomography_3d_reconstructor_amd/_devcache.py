@@ -56,8 +56,8 @@ def _layout(arr):
     return (arr.__array_interface__["data"][0], arr.shape, arr.strides, str(arr.dtype))
 
 
-def put(arr, vol, protect=True):
-    """Remember `vol` as the device copy of `arr`'s CURRENT content.  protect=True (arrays this package creates and
+def put(arr, vol, protect=True, digest=None):
+    """Remember `vol` as the device copy of `arr`'s CURRENT content (digest: its checksum if the caller has taken it already).  protect=True (arrays this package creates and
     returns) write-protects the array under TOMO_READONLY_RESULTS; otherwise -- the default -- its checksum is stored."""
     if not isinstance(arr, np.ndarray) or not arr.flags.c_contiguous:
         return
@@ -66,14 +66,14 @@ def put(arr, vol, protect=True):
         ref = weakref.ref(arr, lambda _r, k=key: _cache.pop(k, None))
     except TypeError:
         return
-    digest = None
     if protect and not WRITEABLE_RESULTS:
+        digest = None
         arr.flags.writeable = False
         b = arr.base                 # ... and what it is a view of (the arrays of _hostbuf are typed views of a byte buffer):
         while isinstance(b, np.ndarray):      # no door may stay open behind a write-protected result
             b.flags.writeable = False
             b = b.base
-    else:
+    elif digest is None:
         digest = checksum(arr)
     _cache[key] = (ref, _layout(arr), digest, vol)
     _cache.move_to_end(key)
@@ -105,6 +105,46 @@ def get(arr):
         STATS["hit_readonly"] += 1
     _cache.move_to_end(id(arr))
     return vol
+
+
+_VERIFY_POOL = []
+
+
+def get_deferred(arr):
+    """get() that does not wait for the checksum: -> (vol, check) -- check is None (write-protected: exact at no cost) or a
+    function that joins the byte-for-byte verification running on a helper thread and says whether `vol` IS the array's content;
+    (None, None): nothing usable is remembered.  The caller computes on `vol` meanwhile and must throw the result away when
+    check() is False (voxel_processor.with_device_volume)."""
+    ent = _cache.get(id(arr))
+    if ent is None:
+        return None, None
+    ref, layout, digest, vol = ent
+    if ref() is not arr or layout != _layout(arr):
+        _cache.pop(id(arr), None)
+        return None, None
+    if not (arr.flags.writeable or _base_writeable(arr)):
+        STATS["hit_readonly"] += 1
+        _cache.move_to_end(id(arr))
+        return vol, None
+    if digest is None:
+        STATS["miss_unverifiable"] += 1
+        _cache.pop(id(arr), None)
+        return None, None
+    if not _VERIFY_POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _VERIFY_POOL.append(ThreadPoolExecutor(1, thread_name_prefix="tomo-verify"))
+    fut = _VERIFY_POOL[0].submit(checksum, arr)
+
+    def check():
+        if fut.result() == digest:
+            STATS["hit_verified"] += 1
+            if id(arr) in _cache:
+                _cache.move_to_end(id(arr))
+            return True
+        STATS["miss_edited"] += 1
+        _cache.pop(id(arr), None)
+        return False
+    return vol, check
 
 
 def invalidate(arr):

@@ -27,6 +27,9 @@ SIGNATURES = {
     "tomo_host_mc_centre_offset": (None, [_c_p, _c_p]),
     "tomo_host_checksum": (_c_i, [_c_p, _c_i64, _c_i, _c_p]),
     "tomo_host_checksum_impl": (_c_i, [_c_p, _c_i64, _c_i, _c_i, _c_p]),
+    "tomo_host_checksum_chunk_bytes": (_c_i64, []),
+    "tomo_host_checksum_part": (_c_i, [_c_p, _c_i64, _c_i64, _c_i, _c_i, _c_p]),
+    "tomo_host_checksum_fold": (_c_i, [_c_p, _c_i64, _c_i64, _c_p]),
     "tomo_host_touch": (_c_i, [_c_p, _c_i64, _c_i]),
     "tomo_host_gather": (_c_i, [_c_p, _c_i64, _c_i64, _c_p, _c_i]),
     "tomo_host_sha256_init": (_c_i, [_c_p]),

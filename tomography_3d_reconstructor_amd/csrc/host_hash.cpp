@@ -117,22 +117,29 @@ void chunk_digest(const uint8_t *p, int64_t n, uint64_t index, uint64_t out[2], 
 // h_out[0..1] = checksum of h_data[0 .. nbytes).  nthreads <= 0: one thread.  Returns 0 or TOMO_E_ARG.
 // impl: 0 = the fastest the CPU offers (AVX2), 1 = the portable loop; same digest (tests compare them)
 TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out);
+TOMO_API int tomo_host_checksum_part(const void *h_part, int64_t nbytes, int64_t first_chunk, int nthreads, int impl, uint64_t *h_dig);
+TOMO_API int tomo_host_checksum_fold(const uint64_t *h_dig, int64_t nchunks, int64_t nbytes, uint64_t *h_out);
 TOMO_API int tomo_host_checksum(const void *h_data, int64_t nbytes, int nthreads, uint64_t *h_out)
 {
     return tomo_host_checksum_impl(h_data, nbytes, nthreads, 0, h_out);
 }
-TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out)
+// The checksum in two steps, for a caller that receives the buffer piece by piece (a download in 128 MiB pieces: piece k is
+// digested while piece k + 1 is on the bus): the digests of the 1 MiB chunks of a PART that starts at a chunk boundary
+// (first_chunk = its offset / 1 MiB; every part but the last a whole number of chunks) -> h_dig[2 per chunk]; then the fold of all
+// chunk digests of the buffer, in order.  tomo_host_checksum = one part + the fold.
+TOMO_API int64_t tomo_host_checksum_chunk_bytes(void) { return CHUNK; }
+
+TOMO_API int tomo_host_checksum_part(const void *h_part, int64_t nbytes, int64_t first_chunk, int nthreads, int impl, uint64_t *h_dig)
 {
-    if (!h_out || nbytes < 0 || (nbytes > 0 && !h_data)) return TOMO_E_ARG;
-    const uint8_t *p = (const uint8_t *)h_data;
-    int64_t nchunks = (nbytes + CHUNK - 1) / CHUNK;
-    std::vector<uint64_t> dig((size_t)nchunks * 2);
+    if (nbytes < 0 || first_chunk < 0 || (nbytes > 0 && (!h_part || !h_dig))) return TOMO_E_ARG;
+    const uint8_t *p = (const uint8_t *)h_part;
+    const int64_t nchunks = (nbytes + CHUNK - 1) / CHUNK;
     if (nthreads < 1) nthreads = 1;
     if ((int64_t)nthreads > nchunks) nthreads = (int)(nchunks > 0 ? nchunks : 1);
     auto work = [&](int64_t c0, int64_t c1) {
         for (int64_t c = c0; c < c1; c++) {
             int64_t off = c * CHUNK, n = nbytes - off < CHUNK ? nbytes - off : CHUNK;
-            chunk_digest(p + off, n, (uint64_t)c, &dig[(size_t)c * 2], impl);
+            chunk_digest(p + off, n, (uint64_t)(first_chunk + c), &h_dig[(size_t)c * 2], impl);
         }
     };
     if (nthreads == 1) {
@@ -146,14 +153,30 @@ TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nth
         }
         for (auto &t : th) t.join();
     }
+    return TOMO_OK;
+}
+
+TOMO_API int tomo_host_checksum_fold(const uint64_t *h_dig, int64_t nchunks, int64_t nbytes, uint64_t *h_out)
+{
+    if (!h_out || nbytes < 0 || nchunks != (nbytes + CHUNK - 1) / CHUNK || (nchunks > 0 && !h_dig)) return TOMO_E_ARG;
     uint64_t h0 = (uint64_t)nbytes ^ P3, h1 = (uint64_t)nbytes * P1;
     for (int64_t c = 0; c < nchunks; c++) {
-        h0 = rotl(h0, 29) * P1 + dig[(size_t)c * 2];
-        h1 = (rotl(h1, 23) ^ dig[(size_t)c * 2 + 1]) * P2;
+        h0 = rotl(h0, 29) * P1 + h_dig[(size_t)c * 2];
+        h1 = (rotl(h1, 23) ^ h_dig[(size_t)c * 2 + 1]) * P2;
     }
     h_out[0] = avalanche(h0);
     h_out[1] = avalanche(h1 ^ h0);
     return TOMO_OK;
+}
+
+TOMO_API int tomo_host_checksum_impl(const void *h_data, int64_t nbytes, int nthreads, int impl, uint64_t *h_out)
+{
+    if (!h_out || nbytes < 0 || (nbytes > 0 && !h_data)) return TOMO_E_ARG;
+    const int64_t nchunks = (nbytes + CHUNK - 1) / CHUNK;
+    std::vector<uint64_t> dig((size_t)nchunks * 2 + 2);
+    int rc = tomo_host_checksum_part(h_data, nbytes, 0, nthreads, impl, dig.data());
+    if (rc != TOMO_OK) return rc;
+    return tomo_host_checksum_fold(dig.data(), nchunks, nbytes, h_out);
 }
 
 // Bring the pages of a freshly allocated HOST buffer in on `nthreads` threads (one byte written per 4 KiB page; the buffer's

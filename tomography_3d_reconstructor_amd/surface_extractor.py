@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _memo, pipeline
-from .voxel_processor import _device, to_device_volume, to_host_array
+from .voxel_processor import _device, to_host_array, with_device_volume
 
 
 class SurfaceExtractor:
@@ -29,18 +29,22 @@ class SurfaceExtractor:
         too large for its 32-bit indices, a failed launch, out of memory.  One line on stderr says which.  Only a
         missing GPU / library raises: that is not a property of the input."""
         try:
-            vol = to_device_volume(volume_data)
             key = (np.ascontiguousarray(slice_depths, dtype=np.float64).tobytes(), float(np.float32(mm_per_pixel_y)),
                    float(np.float32(mm_per_pixel_x)), bool(manifold), bool(add_padding))
-            res = _memo.surfaces.get(vol, key)               # device tensors of an identical earlier call (see _memo)
-            if res is None:
-                res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
-                _memo.surfaces.put(vol, key, res if res is not None else "none")
-            if res is None or isinstance(res, str):
+
+            def work(vol):
+                res = _memo.surfaces.get(vol, key)           # device tensors of an identical earlier call (see _memo)
+                if res is None:
+                    res = pipeline.extract_surface(vol, slice_depths, mm_per_pixel_y, mm_per_pixel_x, manifold, add_padding)
+                    _memo.surfaces.put(vol, key, res if res is not None else "none")
+                if res is None or isinstance(res, str):
+                    return None
+                verts, faces = res
+                return to_host_array(verts.contiguous()), to_host_array(faces.contiguous())
+            out = with_device_volume(volume_data, work)
+            if out is None:
                 return None
-            verts, faces = res
-            vertices = to_host_array(verts.contiguous())
-            faces_np = to_host_array(faces.contiguous())
+            vertices, faces_np = out
             if len(faces_np) == 0:
                 faces_np = np.array([])
             print(f"Surface: {len(vertices)} vertices, {len(faces_np)} faces")

@@ -30,6 +30,20 @@ def to_device_volume(voxel_data):
     return upload_volume(voxel_data)
 
 
+def with_device_volume(voxel_data, fn):
+    """fn(vol) with the device copy of `voxel_data`.  A remembered copy of a WRITEABLE array (the default kind of result) is
+    used speculatively: its byte-for-byte verification (a checksum of the whole array, 5-6 ms per GiB) runs on a helper thread
+    NEXT TO fn -- the device work and the download of fn's result -- and fn runs again on a fresh upload if the array turns out
+    to have been edited.  fn must have no effect but its return value."""
+    if isinstance(voxel_data, np.ndarray):
+        vol, check = _devcache.get_deferred(voxel_data)
+        if vol is not None:
+            res = fn(vol)
+            if check is None or check():
+                return res
+    return fn(upload_volume(voxel_data))
+
+
 def upload_volume(voxel_data):
     """ndarray (nz,ny,nx) -> a FRESH BitVolume (never the cached one: the caller may overwrite it)."""
     a = np.ascontiguousarray(voxel_data)
@@ -63,9 +77,54 @@ def to_host_array(t):
     return host.numpy()
 
 
+PIECE = 128 << 20   # bytes per piece of a download that is checksummed on the way (a whole number of checksum chunks)
+_DIGEST_POOL = []
+
+
+def _download_with_digest(t):
+    """to_host_array for a volume-sized tensor whose checksum is wanted as well (writeable results: _devcache verifies them
+    at the next lookup): the download runs in pieces of PIECE bytes and piece k is digested by a helper thread (native, threaded;
+    the foreign call releases the interpreter lock) while piece k + 1 is on the bus -- the 5-6 ms a checksum of 1 GiB costs
+    disappear behind the 20 ms of its download.  -> (host ndarray, digest as _devcache.checksum gives it)."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    L = pipeline._lib.lib()
+    out = _hostbuf.take(tuple(t.shape), _NP_OF[t.dtype])
+    flat_h = out.reshape(-1).view(np.uint8)
+    flat_d = t.reshape(-1).view(torch.uint8)
+    n = flat_h.shape[0]
+    chunk = int(L.tomo_host_checksum_chunk_bytes())
+    piece = max(chunk, PIECE // chunk * chunk)
+    nchunks = -(-n // chunk)
+    dig = np.zeros(2 * nchunks + 2, dtype=np.uint64)
+    nt = max(1, min(16, os.cpu_count() or 1))
+    if not _DIGEST_POOL:
+        _DIGEST_POOL.append(ThreadPoolExecutor(1, thread_name_prefix="tomo-digest"))
+
+    def digest(a, b):
+        pipeline._lib.check(L.tomo_host_checksum_part(flat_h[a:b].ctypes.data, b - a, a // chunk, nt, 0,
+                                                      dig[2 * (a // chunk):].ctypes.data), "tomo_host_checksum_part")
+    futs = []
+    for a in range(0, n, piece):
+        b = min(n, a + piece)
+        torch.from_numpy(flat_h[a:b]).copy_(flat_d[a:b])      # ordered after the current stream's work; returns when the bytes are there
+        futs.append(_DIGEST_POOL[0].submit(digest, a, b))
+    for f in futs:
+        f.result()
+    res = (ctypes.c_uint64 * 2)()
+    pipeline._lib.check(L.tomo_host_checksum_fold(dig.ctypes.data, nchunks, n, res), "tomo_host_checksum_fold")
+    return out, (int(res[0]), int(res[1]))
+
+
 def to_host_volume(vol):
-    """BitVolume -> fresh host bool ndarray, remembered (write-protected) against its device copy."""
-    out = to_host_array(pipeline.unpack(vol))
+    """BitVolume -> fresh host bool ndarray, remembered against its device copy (writeable and checksummed by default;
+    write-protected under TOMO_READONLY_RESULTS)."""
+    t = pipeline.unpack(vol)
+    if _devcache.WRITEABLE_RESULTS and t.numel() * t.element_size() >= BIG:
+        out, digest = _download_with_digest(t)
+        _devcache.put(out, vol, digest=digest)
+        return out
+    out = to_host_array(t)
     _devcache.put(out, vol)
     return out
 
@@ -241,21 +300,22 @@ class VoxelProcessor:
         """voxel_processor.py:79-97 (binary_opening + `iterations` x binary_closing, 3-D cross).  Like the reference
         (:93-95) a failure of the full sequence falls back to the closings alone; only a missing GPU / library raises
         on the first attempt (there is no CPU path to fall back to)."""
-        vol = to_device_volume(voxel_data)
-        try:
-            # the orchestrator repeats this very call several times: the device result is remembered (see _memo), the
-            # host array is a fresh download every time
-            key = (int(iterations), bool(create_manifold))
-            sm = _memo.smoothed.get(vol, key)
-            if sm is None:
-                sm = pipeline.smooth(vol, iterations, create_manifold)
-                _memo.smoothed.put(vol, key, sm)
-            return to_host_volume(sm)
-        except pipeline._lib.TomoUnavailable:
-            raise
-        except Exception as e:                                           # noqa: BLE001 -- the reference catches Exception here
-            print(f"tomography_3d_reconstructor_amd: smoothing failed ({e}); closings only", file=sys.stderr)
-            return to_host_volume(pipeline.smooth(vol, iterations, False))
+        def work(vol):
+            try:
+                # the orchestrator repeats this very call several times: the device result is remembered (see _memo), the
+                # host array is a fresh download every time
+                key = (int(iterations), bool(create_manifold))
+                sm = _memo.smoothed.get(vol, key)
+                if sm is None:
+                    sm = pipeline.smooth(vol, iterations, create_manifold)
+                    _memo.smoothed.put(vol, key, sm)
+                return to_host_volume(sm)
+            except pipeline._lib.TomoUnavailable:
+                raise
+            except Exception as e:                                       # noqa: BLE001 -- the reference catches Exception here
+                print(f"tomography_3d_reconstructor_amd: smoothing failed ({e}); closings only", file=sys.stderr)
+                return to_host_volume(pipeline.smooth(vol, iterations, False))
+        return with_device_volume(voxel_data, work)
 
     def generate_point_cloud(self, voxel_data: np.ndarray, mm_per_pixel_x: float, mm_per_pixel_y: float,
                              slice_depths: np.ndarray, subsample_factor: int = 1) -> np.ndarray:
