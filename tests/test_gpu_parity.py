@@ -159,7 +159,10 @@ def test_fill_holes_spiral(dev):
 
 
 @pytest.mark.parametrize("shape", [(3, 5, 16), (4, 9, 48), (33, 7, 64), (34, 6, 1040), (35, 3, 2064), (66, 11, 80), (70, 40, 128),
-                                   (2, 8, 32), (1, 8, 32), (5, 6, 20), (40, 12, 1024)])
+                                   (2, 8, 32), (1, 8, 32), (5, 6, 20), (40, 12, 1024),
+                                   # from 128 inner slices on: the kernel that hands the boundary words over inside the workgroup
+                                   # (round 4) -- every remainder of (nz - 2) mod 4, one to three workgroups per column, wide rows
+                                   (130, 5, 48), (131, 4, 64), (132, 3, 80), (133, 5, 32), (200, 3, 2064), (263, 4, 1040), (397, 2, 96)])
 def test_pack_closed_one_pass_vs_oracle(dev, shape, monkeypatch):
     """pipeline.pack_closed (end slices packed + filled, then the fused pack + three-tap stencil kernel) == the oracle's
     _close_volume_ends recurrence == the separate pack / fill / carry-chain kernels, incl. runs that end at the last slice,

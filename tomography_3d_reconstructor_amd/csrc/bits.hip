@@ -304,11 +304,13 @@ __global__ __launch_bounds__(256) void pack_close_kernel(const uint8_t *__restri
 // output of a run is written after one barrier.  Only the two outer waves of a workgroup read a neighbour's slice, so the mask
 // is read (4 zr + 2) / (4 zr) times instead of (zr + 2) / zr (1.016 against 1.0625 at zr = 32).  Outputs za .. zb - 1, zb - za a
 // multiple of PC_U, split into `nwg` workgroups per column and four runs each, a whole number of groups of PC_U slices per run
-// (the first `extra` runs one group longer).  End slices as in pack_close_body.
+// (the first `extra` runs one group longer).  `head` (< PC_U) more slices in FRONT of za -- what (range) mod PC_U leaves -- are
+// written by the first run's wave as well (it knows the word in front of them from the start; a separate launch of the generic
+// kernel for them cost 6 us).  End slices as in pack_close_body.
 __global__ __launch_bounds__(256) void pack_close_ho_kernel(const uint8_t *__restrict__ mask, u64 *__restrict__ bits, int nz, int ny,
                                                             int nx, int wx, int groups, int nwg, int za, int zb, int lo_fixed,
                                                             int hi_fixed, const u64 *__restrict__ below,
-                                                            const u64 *__restrict__ above)
+                                                            const u64 *__restrict__ above, int head)
 {
     __shared__ u64 s_edge[4][2][16];                               // [wave][first / last word of its run][word of the group]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -336,13 +338,19 @@ __global__ __launch_bounds__(256) void pack_close_ho_kernel(const uint8_t *__res
     u64 outer = 0ull;
     u4 t_outer = {0u, 0u, 0u, 0u};
     bool outer_raw = false;
+    const bool with_head = head > 0 && q == 0;                     // (uniform per wave)
     if (w == 0 || w == 3) {
-        const int zo = w == 0 ? z0 - 1 : z1;
+        const int zo = w == 0 ? z0 - 1 - (with_head ? head : 0) : z1;
         if (zo < 0) outer = (below && inw) ? below[(int64_t)y * wx + word] : 0ull;
         else if (zo >= nz) outer = (above && inw) ? above[(int64_t)y * wx + word] : 0ull;
         else if ((zo == 0 && lo_fixed) || (zo == nz - 1 && hi_fixed)) outer = inw ? bits[(int64_t)zo * slice_words + (int64_t)y * wx + word] : 0ull;
         else { t_outer = __builtin_nontemporal_load((const u4 *)(mask + (int64_t)y * nx + (inx ? x : 0) + (int64_t)zo * slice_bytes)); outer_raw = true; }
     }
+    u4 t_head[PC_U - 1];
+#pragma unroll
+    for (int j = 0; j < PC_U - 1; j++)                             // the slices z0 - head .. z0 - 1 (the last `head` entries; the others repeat)
+        t_head[j] = with_head ? __builtin_nontemporal_load((const u4 *)(p - (int64_t)(j < head ? head - j : 1) * slice_bytes))
+                              : (u4){0u, 0u, 0u, 0u};
     u4 t[PC_U];
 #pragma unroll
     for (int j = 0; j < PC_U; j++) t[j] = __builtin_nontemporal_load((const u4 *)(p + (int64_t)j * slice_bytes));
@@ -396,6 +404,23 @@ __global__ __launch_bounds__(256) void pack_close_ho_kernel(const uint8_t *__res
     }
     // prev, cur = the last two words of the run; qq points at the last output
     if (outer_raw) outer = word_fast(t_outer);
+    if (with_head) {
+        // slices z0 - head .. z0 - 1: h[0 .. head); in front of them `outer`, behind them w0.  Written here; the run's own first
+        // output then has h[head - 1] in front of it.
+        u64 h[PC_U - 1];
+#pragma unroll
+        for (int j = 0; j < PC_U - 1; j++) h[j] = word_fast(t_head[j]);          // h[j] = slice z0 - head + j for j < head
+        u64 pv = outer;
+#pragma unroll
+        for (int j = 0; j < PC_U - 1; j++) {
+            if (j < head) {
+                const u64 nxw = j + 1 < head ? h[j + 1] : w0;
+                if (st) qo[(int64_t)(j - head) * slice_words] = h[j] | (pv & nxw);
+                pv = h[j];
+            }
+        }
+        outer = pv;
+    }
     if ((lane & 3) == 0) { s_edge[w][0][lane >> 2] = w0; s_edge[w][1][lane >> 2] = cur; }
     __syncthreads();
     const u64 before = w == 0 ? outer : s_edge[w - 1][1][lane >> 2];
@@ -905,8 +930,8 @@ TOMO_API int tomo_fill_holes_ends(uint64_t *bits, int nz, int ny, int nx, uint64
     return fill_holes_launch(first, last, ny, nx, wx, (u64 *)scratch, (hipStream_t)stream);
 }
 
-// Outputs za .. zb - 1 of the fused pack + stencil pass: long ranges through pack_close_ho_kernel (its first (zb - za) % PC_U
-// slices through the generic kernel, a launch of a few us), short ones through pack_close_kernel in runs of zr slices.
+// Outputs za .. zb - 1 of the fused pack + stencil pass: long ranges through pack_close_ho_kernel (its first run also takes the
+// (zb - za) % PC_U slices in front), short ones through pack_close_kernel in runs of zr slices.
 static int pack_close_launch(const uint8_t *mask, u64 *bits, int nz, int ny, int nx, int wx, int groups, int za, int zb, int lo_fixed,
                              int hi_fixed, const u64 *below, const u64 *above, hipStream_t st)
 {
@@ -915,16 +940,10 @@ static int pack_close_launch(const uint8_t *mask, u64 *bits, int nz, int ny, int
     const int nwg = (G + 4 * (PC_ZR / PC_U) - 1) / (4 * (PC_ZR / PC_U));         // ~PC_ZR slices per wave
     if (handover && zb - za >= 4 * PC_ZR && G >= 4 * nwg) {
         const int head = (zb - za) % PC_U;
-        if (head) {
-            const int64_t blocks0 = ceil_div64((int64_t)ny * groups, 4);
-            if (blocks0 > 0x7fffffff) return TOMO_E_SIZE;
-            hipLaunchKernelGGL(pack_close_kernel, dim3((unsigned)blocks0), dim3(256), 0, st, mask, bits, nz, ny, nx, wx, groups, 1, za,
-                               za + head, lo_fixed, hi_fixed, below, above, PC_ZR);
-        }
         const int64_t blocks = (int64_t)ny * groups * nwg;
         if (blocks > 0x7fffffff) return TOMO_E_SIZE;
         hipLaunchKernelGGL(pack_close_ho_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mask, bits, nz, ny, nx, wx, groups, nwg,
-                           za + head, zb, lo_fixed, hi_fixed, below, above);
+                           za + head, zb, lo_fixed, hi_fixed, below, above, head);
         return tomo_status();
     }
     // a short range (the slices at an end of a slab) in runs of 8: four times the waves, a quarter of the serial march each
