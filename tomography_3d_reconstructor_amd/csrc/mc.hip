@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(MC3_BLK) void mc3_eval_kernel(const float *__restri
     }
 }
 
-// ---- scan: block sums -> exclusive prefixes, totals and the per-slice tables; its last part writes the offsets of the
+// ---- scan: block sums -> exclusive prefixes, totals and the per-slice tables; mc3_bands_kernel then writes the offsets of the
 // sort's segments.  slice_tab: sliceA[Nz + 1] | sliceB[Nz + 1] | offsets[(NB + 1) Nz + 1] | merge3[3]  (uint32), NB =
 // TOMO_SORT_NB(Ny): per slice NB bands of tomo_sort_band(Ny) owner rows of in-plane vertices, then the between-plane vertices.
 // In a plane the vertices arrive grouped by owner row and a vertex of owner row Y has its key y' in [Y, Y + 1] * mm_y, so the
@@ -1042,7 +1042,6 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
 {
     __shared__ u32 lds[3 * 16 + 3];
     u64 totals[3];
-    const bool ov_before = tot[3] != 0;                         // (read before this kernel adds its own flags)
     scan_small_inplace<3>(blk3, nblk, nblk, totals, lds);       // ends with a barrier: the prefixes are visible to every thread
     const u64 na = tot[0];
     const u64 totA64 = totals[0], totB64 = totals[1], totT64 = totals[2];
@@ -1068,44 +1067,48 @@ __global__ __launch_bounds__(1024) void mc3_scan_kernel(const McGrid g, const u3
     if (totA64 + totB64 > (u64)cap_v) ov |= 2ull;
     if (totT64 > (u64)cap_f) ov |= 4ull;
     if (!fits) ov |= 1ull;
-    const bool overflow = ov != 0 || ov_before;
     if (threadIdx.x == 0) {
         tot[1] = totA64 + totB64;
         tot[2] = totT64;
         if (ov) atomicOr((unsigned long long *)&tot[3], (unsigned long long)ov);
     }
-    // ---- the offsets of the sort's segments (round 4: was mc3_bands_kernel, a launch of 5 us): segment (Z, b), b < NB the band of
-    //      owner rows [b, b + 1) * tomo_sort_band(Ny) of plane Z, b == NB the between-plane bucket; on overflow every segment is
-    //      empty: the sort touches nothing.  The slice tables were written by this workgroup: visible after the barrier.
-    __threadfence_block();
-    __syncthreads();
-    const int NB = TOMO_SORT_NB(g.Ny);
-    const int64_t nsegs = (int64_t)(NB + 1) * Nz;
-    u32 *offsets = slice_tab + 2 * (Nz + 1), *merge3 = offsets + nsegs + 1;
-    for (int64_t i = threadIdx.x; i <= nsegs; i += 1024) {
-        if (i == nsegs) {
-            offsets[nsegs] = overflow ? 0u : sliceA[Nz] + sliceB[Nz];
-            // slab 0's between-plane bucket and slab 1's plane (uq3_merge_kernel; Nz >= 2 always)
-            merge3[0] = overflow ? 0u : sliceA[1] + sliceB[0];
-            merge3[1] = overflow ? 0u : sliceA[1] + sliceB[1];
-            merge3[2] = overflow ? 0u : sliceA[Nz >= 2 ? 2 : 1] + sliceB[1];
-            merge3[3] = 0u;
-            continue;
-        }
-        const int Z = (int)(i / (NB + 1)), b = (int)(i - (int64_t)Z * (NB + 1));
-        u32 o = 0u;
-        if (!overflow) {
-            if (b == NB) {
-                o = sliceA[Z + 1] + sliceB[Z];
-            } else {
-                // in-plane vertices before the first voxel of row (Z, b * BAND): the list position of that voxel, then its prefix
-                const u64 s = seg_aoff[((int64_t)Z * g.Ny + (int64_t)b * tomo_sort_band(g.Ny)) * g.segs_per_row];
-                const u32 a = s < na ? blk3[s >> 8] + MC3_LOC_A(vox_loc[s]) : sliceA[Nz];
-                o = a + sliceB[Z];
-            }
-        }
-        offsets[i] = o;
+}
+
+// one thread per sort segment (Z, b): b < NB the band of owner rows [b, b + 1) * tomo_sort_band(Ny) of plane Z, b == NB the
+// between-plane bucket; on overflow (tot[3]) every segment is empty: the sort touches nothing
+__global__ __launch_bounds__(256) void mc3_bands_kernel(const McGrid g, const u32 *__restrict__ seg_aoff,
+                                                        const u32 *__restrict__ vox_loc, const u32 *__restrict__ blk3,
+                                                        int64_t nblk, u32 *__restrict__ slice_tab, const u64 *__restrict__ tot)
+{
+    const int Nz = g.Nz, NB = TOMO_SORT_NB(g.Ny);
+    const int64_t nseg = (int64_t)(NB + 1) * Nz, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 *sliceA = slice_tab, *sliceB = slice_tab + (Nz + 1);
+    u32 *offsets = slice_tab + 2 * (Nz + 1), *merge3 = offsets + nseg + 1;
+    const bool ov = tot[3] != 0;
+    const u64 na = tot[0];
+    if (i == nseg) {
+        offsets[nseg] = ov ? 0u : sliceA[Nz] + sliceB[Nz];
+        // slab 0's between-plane bucket and slab 1's plane (uq3_merge_kernel; Nz >= 2 always)
+        merge3[0] = ov ? 0u : sliceA[1] + sliceB[0];
+        merge3[1] = ov ? 0u : sliceA[1] + sliceB[1];
+        merge3[2] = ov ? 0u : sliceA[Nz >= 2 ? 2 : 1] + sliceB[1];
+        merge3[3] = 0u;                                           // the ticket word of uq3_sortrank_kernel (mesh.hip)
+        return;
     }
+    if (i > nseg) return;
+    const int Z = (int)(i / (NB + 1)), b = (int)(i - (int64_t)Z * (NB + 1));
+    u32 o = 0u;
+    if (!ov) {
+        if (b == NB) {
+            o = sliceA[Z + 1] + sliceB[Z];
+        } else {
+            // in-plane vertices before the first voxel of row (Z, b * BAND): the list position of that voxel, then its prefix
+            const u64 s = seg_aoff[((int64_t)Z * g.Ny + (int64_t)b * tomo_sort_band(g.Ny)) * g.segs_per_row];
+            const u32 a = s < na ? blk3[s >> 8] + MC3_LOC_A(vox_loc[s]) : sliceA[Nz];
+            o = a + sliceB[Z];
+        }
+    }
+    offsets[i] = o;
 }
 
 // ---- vertices: final coordinates (surface_extractor.py:57-65, :82-113 -- the arithmetic of vertex_finalize_kernel),
@@ -1339,9 +1342,12 @@ TOMO_API int tomo_mc3_scan(int Nz, int Ny, int Nx, int xorg, const uint32_t *seg
     if (cap_v >= 0x7fffffffll || cap_f >= 0x7fffffffll) return TOMO_E_SIZE;
     McGrid g; g.Nz = Nz; g.Ny = Ny; g.Nx = Nx; g.pitch = 0; g.xorg = xorg; g.iso = 0.0;
     g.segs_per_row = (int)tomo_mc_segments_per_row(Nx, xorg);
-    if (tomo_mc3_sort_segments(Nz, Ny) + 1 > 0x7fffffff) return TOMO_E_SIZE;
     hipLaunchKernelGGL(mc3_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, seg_aoff, vox_loc, cap, blk3,
                        ceil_div64(cap, MC3_BLK), slice_tab, (u64 *)tot, cap_v, cap_f);
+    const int64_t nseg = tomo_mc3_sort_segments(Nz, Ny);
+    if (nseg + 1 > 0x7fffffff) return TOMO_E_SIZE;
+    hipLaunchKernelGGL(mc3_bands_kernel, dim3((unsigned)ceil_div64(nseg + 1, 256)), dim3(256), 0, (hipStream_t)stream, g, seg_aoff,
+                       vox_loc, (const u32 *)blk3, ceil_div64(cap, MC3_BLK), slice_tab, (const u64 *)tot);
     return tomo_status();
 }
 

@@ -417,7 +417,7 @@ TOMO_API int tomo_mesh_unique_presorted(const float *vpos, const unsigned long l
 
 // ------------------------------------------------------------------------------------------ mc3: sort + rank
 // The unique stage of the mc3 chain (mc.hip): vertices arrive FINALISED as 16-byte records {z', y', x', id}, already
-// partitioned into the 2 Nz buckets with their 32-bit sort keys; the offsets (mc3_scan_kernel) cut every plane's bucket
+// partitioned into the 2 Nz buckets with their 32-bit sort keys; the offsets (mc3_bands_kernel) cut every plane's bucket
 // further into bands of owner rows -- the order inside a plane is local to a row.  One segmented sort inside the segments, the clamped-run merge of the first two buckets (see uq_merge_kernel), and one gather that writes
 // the rows in order, table[id] = position, and counts every place where the result does not ascend STRICTLY: with a
 // count of zero the sorted position is np.unique's index (no duplicate rows, no rounding coincidence) -- otherwise the
@@ -513,7 +513,7 @@ TOMO_API int tomo_mc3_sort_rank_top(const float *vrec, uint32_t *keys, uint32_t 
 {
     if (!vrec || !keys || !idx || !slice_tab || !tot || !uniq || !table || !workspace || cap_v <= 0 || Nz < 1 || Ny < 1) return TOMO_E_ARG;
     if (cap_v >= 0x7fffffffll || Nz > UQ_MAX_SLABS) return TOMO_E_SIZE;
-    // segments: per slice TOMO_SORT_NB(Ny) bands of owner rows of the plane, then the between-plane bucket (mc3_scan_kernel)
+    // segments: per slice TOMO_SORT_NB(Ny) bands of owner rows of the plane, then the between-plane bucket (mc3_bands_kernel)
     const int64_t nseg = (int64_t)(TOMO_SORT_NB(Ny) + 1) * Nz;
     if (nseg >= 0x7fffffffll) return TOMO_E_SIZE;
     Uq3Layout L = uq3_layout(cap_v, nseg);

@@ -68,14 +68,33 @@ md = ["# Round profile `%s` -- `rocprofv3 --kernel-trace --stats -- python3 benc
       "\n| kernel | calls | avg us | ms per pass | % |\n|---|---|---|---|---|"]
 for n, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     md.append("| `%s` | %d | %.2f | %.3f | %.2f |" % (n[:70], len(v), sum(v) / len(v), sum(v) / PASSES / 1e3, 100 * sum(v) / tot))
-md.append("\n(`at::native::*` kernels are the synthetic-mask generation before the timed region.)\n")
+md.append("\n(`at::native::*` kernels are the synthetic-mask generation before the timed region.  The default command puts the front of a pass -- "
+          "pack + close + smoothing -- on a second stream behind the field kernel of the pass before: kernels that then run next to each other "
+          "are longer in this table than alone.)\n")
+trace1 = one("trace1/**/*kernel_trace.csv")
+if trace1:
+    acc1 = collections.OrderedDict()
+    for r in csv.DictReader(open(trace1)):
+        acc1.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    tot1 = sum(sum(v) for k, v in acc1.items() if not k.startswith(("void at::", "void (anonymous", "__amd")))
+    md.append("\n## The same passes with `--one-stream` (every kernel alone on the GPU): avg us per launch\n")
+    md.append("Bench line: `%s`\n" % last_json(os.path.join(out, "bench_trace1.log")))
+    md.append("| kernel | calls | avg us | ms per pass |\n|---|---|---|---|")
+    for n, v in sorted(acc1.items(), key=lambda kv: -sum(kv[1])):
+        if n.startswith(("void at::", "void (anonymous", "__amd")):
+            continue
+        md.append("| `%s` | %d | %.2f | %.3f |" % (n[:70], len(v), sum(v) / len(v), sum(v) / PASSES / 1e3))
+    md.append("\nhot-path kernels per pass: %.3f ms\n" % (tot1 / PASSES / 1e3))
+    s1 = one("trace1/**/*kernel_stats.csv")
+    if s1:
+        shutil.copy(s1, os.path.join(out, "%s_bench_kernel_stats_one_stream.csv" % tag))
 md.append("\n## PMC passes (separate runs of the same command: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`), per dispatch, KB\n")
 md.append("Calibration (round 1): `pack16_kernel` reads exactly 1 GiB (1 048 576 KB) with 16 B/lane loads; its raw FETCH_SIZE shows the 1/2 factor "
           "the MI355X guide documents for coalesced reads on gfx950, so reads are doubled below (`pack_close_ho_kernel`, round 4, reads 130/128 GiB: only the outer waves of a workgroup "
           "re-read a neighbour's slice; rounds 1-3: 34/32).  WRITE_SIZE is exact.\n")
 md.append("| kernel | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM bytes = 2*FETCH + WRITE |\n|---|---|---|---|")
 for sub in ("pack_close_ho_kernel", "pack_close_kernel", "morph_wave32_kernel<4, 6", "morph_wave32_kernel<4, 5", fk, "mc_classify_bits_kernel", "mc3_list_kernel", "mc3_eval_kernel",
-            "mc3_vertices_kernel", "uq3_sortrank_kernel<2560>", "rocprim", "uq3_rank_kernel", "mc3_faces_kernel"):
+            "mc3_vertices_kernel", "uq3_sortrank_kernel", "rocprim", "uq3_rank_kernel", "mc3_faces_kernel"):
     a, b = find(fetch, sub), find(write, sub)
     if a is not None and b is not None:
         md.append("| `%s` | %.0f | %.0f | %.3e |" % (sub, a, b, (2 * a + b) * 1024))
