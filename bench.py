@@ -884,13 +884,20 @@ def run(args, world, cpu=None):
                                   "shared-plane rows in fixed-capacity messages, global indices from device-side counts); the "
                                   "first pass of a job is always the exact one (four host round trips)"}})
     # ------------------------------------------------------------------ is it the reference's mesh?  (every run says so itself)
-    parity, _ = verify((gz, ny, nx), blk) if not args.no_parity else ({"parity_in_run": "not checked (--no-parity)"}, None)
-    nverts, nfaces = parity.get("n_vertices", 0), parity.get("n_faces", 0)
-    if args.no_parity and res is not None:
-        cnt = torch.tensor([int(res[0].shape[0]), int(res[1].shape[0])], dtype=torch.int64, device=rdev)
-        if dist:
-            td.all_reduce(cnt)
-        nverts, nfaces = [int(c) for c in cnt.cpu()]
+    job = None                                        # (verify may have to free this rank's share of the job: no second reference to it)
+    if args.no_parity:
+        parity = {"parity_in_run": "not checked (--no-parity)"}
+        nverts = nfaces = 0
+        if res is not None:
+            cnt = torch.tensor([int(res[0].shape[0]), int(res[1].shape[0])], dtype=torch.int64, device=rdev)
+            if dist:
+                td.all_reduce(cnt)
+            nverts, nfaces = [int(c) for c in cnt.cpu()]
+        res = None
+    else:
+        res = None
+        parity, _ = verify((gz, ny, nx), blk)
+        nverts, nfaces = parity.get("n_vertices", 0), parity.get("n_faces", 0)
     failed = parity["parity_in_run"] is False
     pass_floor_bytes = 5.0 * total_voxels            # 1 B mask in + 4 B f32 field out per voxel: what a pass cannot avoid moving
     out = {
