@@ -102,3 +102,33 @@ def test_retry_port_is_probed_by_rank_0_and_shared():
         assert bench.retry_port(dict(env0, RANK="5"), wait_s=5.0) == p0
     finally:
         busy.close()
+
+
+def test_golden_lookup_and_the_counter_file_tied_to_the_kernel_source(tmp_path, monkeypatch):
+    """bench.expected_hashes: the fixture a run's parity_in_run is checked against (reference-derived up to 1024^3, oracle-derived
+    for BASELINE configs[3] / [4], none for other stacks); bench.field_pmc_for_this_build: counter bytes are used only for the
+    build of csrc/field.hip they were measured on."""
+    import hashlib
+    import json
+    e = bench.expected_hashes((1024, 1024, 1024))
+    assert e and "ellipsoid_hashes.json (reference)" in e["source"] and (e["nv"], e["nf"]) == (3538048, 7076092) and len(e["v"]) == 64
+    e4, e5 = bench.expected_hashes((2048, 1024, 1024)), bench.expected_hashes((4096, 2048, 2048))
+    assert e4 and e5 and "oracle-derived" in e4["source"] and "oracle-derived" in e5["source"] and e5["nv"] == 23876144
+    assert bench.expected_hashes((8192, 1024, 1024)) is None and bench.expected_hashes((100, 100, 100)) is None
+    p, b = bench.field_pmc_for_this_build()                       # the committed r04 file matches the committed kernel
+    src = os.path.join(ROOT, "tomography_3d_reconstructor_amd", "csrc", "field.hip")
+    assert p is not None and b > 4.5e9
+    assert json.load(open(os.path.join(ROOT, p)))["field_hip_sha256"] == hashlib.sha256(open(src, "rb").read()).hexdigest()
+    stale = tmp_path / "pmc.json"
+    stale.write_text(json.dumps({"field_hip_sha256": "0" * 64, "hbm_bytes_per_launch": 1.0}))
+    monkeypatch.setattr(bench, "FIELD_PMCS", [str(stale)])
+    assert bench.field_pmc_for_this_build() == (None, None)       # a file of another build is not used
+
+
+def test_cpu_baseline_all_core_leg_counts_like_the_one_thread_run():
+    """bench.cpu_baseline: the all-core leg (Z-chunks with 13 spare slices either side, a process pool) finds exactly the
+    vertices and triangles of the one-thread run on the whole stack."""
+    r = bench.cpu_baseline(96, workers=3)
+    assert r["cores"] == 1 and r["kind"] == "port" and r["all_cores"]["cores"] == 3
+    assert (r["all_cores"]["n_vertices"], r["all_cores"]["n_faces"]) == (r["n_vertices"], r["n_faces"]) and r["n_vertices"] > 0
+    assert "counts equal to the one-thread run: True" in r["all_cores"]["sample"]
