@@ -30,7 +30,7 @@ def single_gpu(v, depths, mm_y, mm_x, dev):
     return got[0].cpu().numpy(), got[1].cpu().numpy()
 
 
-def run_passes(world, volumes, depths, mm_y, mm_x, dev):
+def run_passes(world, volumes, depths, mm_y, mm_x, dev, z_cuts=None):
     """One SlabJob per rank thread, one pass per entry of `volumes` -> ([(verts, faces, n_global) per pass], [job stats])."""
     nz, ny, nx = volumes[0].shape
     out = [[None] * world for _ in volumes]
@@ -39,7 +39,7 @@ def run_passes(world, volumes, depths, mm_y, mm_x, dev):
 
     def target(c):
         try:
-            job = slab.SlabJob(nz, ny, nx, c)
+            job = slab.SlabJob(nz, ny, nx, c, z_cuts=z_cuts)
             with torch.cuda.stream(torch.cuda.Stream()):
                 for p, v in enumerate(volumes):
                     mask = torch.from_numpy(np.ascontiguousarray(v[job.z0:job.z1]).view(np.uint8)).to(dev)
@@ -386,3 +386,41 @@ def test_a_cut_face_too_long_for_the_sort_kernel_takes_the_library_path(dev):
     for per_rank, r in zip(out, refs):
         check_pass(per_rank, r)
     assert all(s[1] >= 1 for s in stats), stats             # the pass that met the cut was redone, on every rank
+
+
+def test_slabs_of_unequal_thickness_on_the_hip_engine(dev):
+    """SlabJob(z_cuts=...) (round 4: slabs of equal WORK): three ranks with 150 / 21 / 213 slices -- a thin slab between two thick
+    ones, on either side of the one-exchange front's 128-slice limit -- exact pass, then two deferred ones: bytes-equal to the
+    single-GPU mesh; and the cuts work_balanced_cuts derives from a pass are the same on every rank."""
+    if not (pipeline.MC3 and pipeline.NA_HINTS and slab.DEFERRED_NUMBERING):
+        pytest.skip("needs the mc3 chain with size hints")
+    nz, ny, nx = 384, 96, 144
+    v = blob(nz, ny, nx, 1.0, 9)
+    depths = np.concatenate([np.full(100, 0.5), np.full(184, 0.25), np.full(100, 0.75)])
+    ref = single_gpu(v, depths, 0.7, 0.9, dev)
+    for cuts in ([0, 150, 171, 384], [0, 130, 258, 384]):
+        out, stats = run_passes(3, [v, v, v], depths, 0.7, 0.9, dev, z_cuts=cuts)
+        for per_rank in out:
+            check_pass(per_rank, ref)
+        assert stats == [(2, 0)] * 3, stats
+    got = [None] * 3
+    errs = []
+
+    def target(c):
+        try:
+            job = slab.SlabJob(nz, ny, nx, c)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                mask = torch.from_numpy(np.ascontiguousarray(v[job.z0:job.z1]).view(np.uint8)).to(dev)
+                job.run(mask, depths, 0.7, 0.9)
+                got[c.rank] = (job.work_balanced_cuts(depths, 0.3, align=4), job.slice_vertex_counts(depths))
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+            raise
+    ts = [threading.Thread(target=target, args=(c,)) for c in slab.ThreadComm.make(3)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    assert got[0][0] == got[1][0] == got[2][0] and got[0][0][0] == 0 and got[0][0][-1] == nz
+    assert np.array_equal(got[0][1], got[2][1]) and int(got[0][1].sum()) == len(ref[0])
+    thick = np.diff(got[0][0])
+    assert thick[1] < thick[0] and thick[1] < thick[2]              # the middle of the body holds the most surface per slice
